@@ -1,0 +1,111 @@
+/*
+ * veon_hip.h -- C ABI of libveon_hip.so: the MI355X (gfx950) drop-in for the
+ * native half of VEON's Lift-Splat hot path.
+ *
+ * Conventions (mirroring the reference launchers, which are already plain C
+ * functions over raw pointers -- mmdet3d/ops/bev_pool_v2/src/bev_pool.cpp:7-14):
+ *   - every pointer is a DEVICE pointer owned by the caller; the library never
+ *     allocates, frees or retains memory across calls (workspaces are passed in);
+ *   - every launch goes to the `stream` argument (a hipStream_t passed as
+ *     void*; NULL = the null stream), is asynchronous and is hipGraph-capturable;
+ *   - every entry point returns VEON_OK (0) or a VEON_ERR_* code; nothing is
+ *     printed.  The reference returns void and checks nothing;
+ *   - index ARRAYS are int32 (the reference ABI); offsets derived from them are
+ *     computed in 64 bits (the reference overflows int32 at batch >= 14 with
+ *     C = 256: bev_pool_cuda.cu:41,46).
+ * Paths below are relative to the reference tree.
+ */
+#ifndef VEON_HIP_H_
+#define VEON_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VEON_ABI_VERSION 1
+
+#define VEON_OK 0
+#define VEON_ERR_BAD_ARG 1    /* null pointer, negative size, unsupported shape */
+#define VEON_ERR_LAUNCH 2     /* hipGetLastError() != hipSuccess after launch   */
+#define VEON_ERR_WORKSPACE 3  /* workspace too small                            */
+
+/* output layouts of the fused forward */
+#define VEON_LAYOUT_BZYXC 0 /* (B,Z,Y,X,C): QuickCumsumCuda's `out`, bev_pool.py:27 */
+#define VEON_LAYOUT_BCZYX 1 /* (B,C,Z,Y,X): bev_pool_v2()'s return, bev_pool.py:91  */
+
+int veon_abi_version(void);
+const char *veon_status_string(int status);
+
+/*
+ * Drop-in for `void bev_pool_v2(int c, int n_intervals, ...)`
+ * (mmdet3d/ops/bev_pool_v2/src/bev_pool_cuda.cu:125-131, declared
+ * bev_pool.cpp:7-9).  Same argument order and meaning; `out` is
+ * [n_voxels][c], must be zero-filled by the caller (bev_pool.py:27) and only
+ * rows named by ranks_bev[interval_starts[i]] are written.  Any interval
+ * order is accepted.  Per (interval, channel) the sum is a serial fmaf chain
+ * in storage order, as the reference kernel's (:38-43).
+ */
+int veon_bev_pool_v2_fwd(int c, int n_intervals, const float *depth,
+                         const float *feat, const int *ranks_depth,
+                         const int *ranks_feat, const int *ranks_bev,
+                         const int *interval_starts,
+                         const int *interval_lengths, float *out, void *stream);
+
+/*
+ * Drop-in for `void bev_pool_v2_grad(int c, int n_intervals, ...)`
+ * (bev_pool_cuda.cu:133-140, declared bev_pool.cpp:11-14).  Intervals are over
+ * the ranks_feat-sorted point list (bev_pool.py:47-57).  depth_grad / feat_grad
+ * must be zero-filled by the caller (bev_pool.py:67-68); out_grad is
+ * [n_voxels][c].
+ */
+int veon_bev_pool_v2_bwd(int c, int n_intervals, const float *out_grad,
+                         const float *depth, const float *feat,
+                         const int *ranks_depth, const int *ranks_feat,
+                         const int *ranks_bev, const int *interval_starts,
+                         const int *interval_lengths, float *depth_grad,
+                         float *feat_grad, void *stream);
+
+/*
+ * Fused forward: zero-fill + pool (+ layout permute) in ONE pass; every
+ * element of `out` is written exactly once, so `out` may be uninitialised.
+ * Replaces the three full-volume passes of the reference
+ * (new_zeros bev_pool.py:27, kernel store bev_pool_cuda.cu:46-47,
+ * permute().contiguous() bev_pool.py:91).
+ *
+ * Precondition (what voxel_pooling_prepare_v2 produces,
+ * view_transformer_raw.py:287-299): intervals ascending and unique in
+ * ranks_bev[interval_starts[i]], all < batch * voxels_per_batch.
+ * `tile_first` is optional (NULL = search in-kernel): see
+ * veon_bev_pool_tile_table().
+ */
+int veon_bev_pool_v2_fwd_fused(int c, int n_intervals, int batch,
+                               int64_t voxels_per_batch, const float *depth,
+                               const float *feat, const int *ranks_depth,
+                               const int *ranks_feat, const int *ranks_bev,
+                               const int *interval_starts,
+                               const int *interval_lengths,
+                               const int *tile_first, float *out,
+                               int out_layout, void *stream);
+
+/* Voxels per tile the fused kernels use for `out_layout` and channel count
+ * (tile t covers voxel ranks [t*V, (t+1)*V) of one batch element). */
+int veon_bev_pool_tile_voxels(int c, int out_layout);
+
+/*
+ * Fill tile_first[0 .. n_tiles] (n_tiles = batch * ceil(voxels_per_batch / V))
+ * with the index of the first interval whose voxel rank is >= the tile's first
+ * rank (tile_first[n_tiles] = n_intervals).  Cache it beside the five rank
+ * arrays (the accelerate=True path, view_transformer_raw.py:196-215).
+ */
+int veon_bev_pool_tile_table(int n_intervals, int batch,
+                             int64_t voxels_per_batch, int tile_voxels,
+                             const int *ranks_bev, const int *interval_starts,
+                             int *tile_first, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VEON_HIP_H_ */

@@ -1,0 +1,95 @@
+"""ctypes binding of libveon_hip.so (the C ABI declared in include/veon_hip.h).
+
+The product path has NO fallback: if the library is missing or a tensor is not
+on a ROCm device, the call raises.  Pointers are passed as raw device addresses
+(``tensor.data_ptr()``) and the launch goes to PyTorch's current HIP stream, so
+the ops are hipGraph-capturable and race-free against surrounding torch ops
+(the reference launches on the legacy default stream, bev_pool_cuda.cu:127,136).
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libveon_hip.so')
+_lib = None
+
+_vp = ctypes.c_void_p
+_ci = ctypes.c_int
+_i64 = ctypes.c_int64
+_cf = ctypes.c_float
+
+_SIGNATURES = {
+    'veon_abi_version': (_ci, []),
+    'veon_status_string': (ctypes.c_char_p, [_ci]),
+    'veon_bev_pool_v2_fwd': (_ci, [_ci, _ci] + [_vp] * 8 + [_vp]),
+    'veon_bev_pool_v2_bwd': (_ci, [_ci, _ci] + [_vp] * 10 + [_vp]),
+    'veon_bev_pool_v2_fwd_fused': (_ci, [_ci, _ci, _ci, _i64] + [_vp] * 9 + [_ci, _vp]),
+    'veon_bev_pool_tile_voxels': (_ci, [_ci, _ci]),
+    'veon_bev_pool_tile_table': (_ci, [_ci, _ci, _i64, _ci, _vp, _vp, _vp, _vp]),
+}
+
+LAYOUT_BZYXC = 0
+LAYOUT_BCZYX = 1
+
+
+class VeonHipError(RuntimeError):
+    pass
+
+
+def declared_symbols():
+    """Every entry point include/veon_hip.h declares (checked by the CPU tests)."""
+    return sorted(_SIGNATURES)
+
+
+def register(name, restype, argtypes):
+    _SIGNATURES[name] = (restype, argtypes)
+    if _lib is not None:
+        fn = getattr(_lib, name)
+        fn.restype, fn.argtypes = restype, argtypes
+
+
+def lib():
+    """Load libveon_hip.so; raise (never fall back) when it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise VeonHipError(
+                'veon_amd: %s not found -- build it with `python -m veon_amd.build` '
+                '(hipcc --offload-arch=gfx950). There is no CPU fallback.' % LIB_PATH)
+        _lib = ctypes.CDLL(LIB_PATH)
+        for name, (restype, argtypes) in _SIGNATURES.items():
+            fn = getattr(_lib, name)
+            fn.restype, fn.argtypes = restype, argtypes
+    return _lib
+
+
+def check(status, what):
+    if status != 0:
+        msg = lib().veon_status_string(status).decode()
+        raise VeonHipError('%s failed: %s (status %d)' % (what, msg, status))
+
+
+def require_device(*tensors):
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise VeonHipError(
+                'veon_amd HIP op called with a %s tensor: the op runs only on a '
+                'ROCm device (no CPU path).' % t.device)
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise VeonHipError('tensors on different devices: %s vs %s' % (dev, t.device))
+    return dev
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def stream_ptr(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)

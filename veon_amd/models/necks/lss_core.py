@@ -1,0 +1,170 @@
+"""Shared Lift-Splat machinery of the view transformers.
+
+The reference carries this code twice, byte-identical
+(mmdet3d/models/necks/view_transformer.py:66-295 and
+view_transformer_raw.py:74-337); here it lives once and both plugin classes
+derive from it.  Method names, argument order, attributes and return values
+are the reference's: ``create_grid_infos``, ``create_frustum``,
+``get_lidar_coor``, ``init_acceleration_v2``, ``voxel_pooling_prepare_v2``,
+``voxel_pooling_v2``, ``pre_compute``, ``view_transform_core``,
+``view_transform``; ``D``, ``frustum``, ``grid_lower_bound``,
+``grid_interval``, ``grid_size``, ``accelerate``, ``initial_flag``,
+``ranks_*``, ``interval_*``.
+"""
+import torch
+import torch.nn as nn
+
+from ...ops.bev_pool_v2 import bev_pool as _bp
+from ...ops.bev_pool_v2.bev_pool import bev_pool_v2
+from ... import lss_prepare as _prep
+
+try:  # pragma: no cover - mmcv is absent from the build image
+    from mmcv.runner import BaseModule as _Base
+except Exception:
+    _Base = nn.Module
+
+
+class LSSCore(_Base):
+    """Geometry + index preparation + pooling; subclasses add the depth net."""
+
+    # view_transformer.py returns (bev_feat, depth) from view_transform_core
+    # (:284), view_transformer_raw.py only bev_feat (:332).
+    _core_returns_depth = True
+
+    def _init_lss(self, grid_config, input_size, downsample, out_channels,
+                  accelerate, sid, collapse_z):
+        self.grid_config = grid_config
+        self.downsample = downsample
+        self.create_grid_infos(**grid_config)
+        self.sid = sid
+        self.frustum = self.create_frustum(grid_config['depth'], input_size,
+                                           downsample)
+        self.out_channels = out_channels
+        self.accelerate = accelerate
+        self.initial_flag = True
+        self.collapse_z = collapse_z
+
+    # ------------------------------------------------------------------ grid
+    def create_grid_infos(self, x, y, z, **kwargs):
+        """view_transformer_raw.py:74-89: float32 tensors, size = (hi-lo)/step
+        evaluated in Python doubles first."""
+        axes = (x, y, z)
+        self.grid_lower_bound = torch.Tensor([a[0] for a in axes])
+        self.grid_interval = torch.Tensor([a[2] for a in axes])
+        self.grid_size = torch.Tensor([(a[1] - a[0]) / a[2] for a in axes])
+
+    def create_frustum(self, depth_cfg, input_size, downsample):
+        """view_transformer_raw.py:91-119 -> (D, Hf, Wf, 3) = (x_pix, y_pix, d)."""
+        h_in, w_in = input_size
+        hf, wf = h_in // downsample, w_in // downsample
+        d = torch.arange(*depth_cfg, dtype=torch.float)
+        self.D = d.shape[0]
+        if self.sid:
+            # spacing-increasing discretisation (:105-110)
+            k = torch.arange(self.D).float()
+            cfg = torch.tensor(depth_cfg).float()
+            d = torch.exp(torch.log(cfg[0]) + k / (self.D - 1) *
+                          torch.log((cfg[1] - 1) / cfg[0]))
+        xs = torch.linspace(0, w_in - 1, wf, dtype=torch.float)
+        ys = torch.linspace(0, h_in - 1, hf, dtype=torch.float)
+        fr = torch.empty(self.D, hf, wf, 3, dtype=torch.float)
+        fr[..., 0] = xs.view(1, 1, wf)
+        fr[..., 1] = ys.view(1, hf, 1)
+        fr[..., 2] = d.view(self.D, 1, 1)
+        return fr
+
+    # -------------------------------------------------------------- geometry
+    def get_lidar_coor(self, sensor2ego, ego2global, cam2imgs, post_rots,
+                       post_trans, bda):
+        """Frustum points in the ego frame, (B, N, D, Hf, Wf, 3)
+        (view_transformer_raw.py:121-158).  ``ego2global`` is accepted and
+        unused, as in the reference."""
+        return _prep.get_lidar_coor(self.frustum, sensor2ego, cam2imgs,
+                                    post_rots, post_trans, bda)
+
+    # ----------------------------------------------------------- index half
+    def voxel_pooling_prepare_v2(self, coor):
+        """view_transformer_raw.py:244-302 -> (ranks_bev, ranks_depth,
+        ranks_feat, interval_starts, interval_lengths) int32, or 5 x None."""
+        return _prep.voxel_pooling_prepare_v2(
+            coor, self.grid_lower_bound, self.grid_interval, self.grid_size)
+
+    def init_acceleration_v2(self, coor):
+        """view_transformer_raw.py:196-215: cache the five rank tensors (plus,
+        here, the fused kernel's tile table)."""
+        ranks_bev, ranks_depth, ranks_feat, interval_starts, interval_lengths \
+            = self.voxel_pooling_prepare_v2(coor)
+        if ranks_bev is None:
+            raise RuntimeError('accelerate=True but no frustum point falls '
+                               'inside the grid')
+        self.ranks_bev = ranks_bev.int().contiguous()
+        self.ranks_feat = ranks_feat.int().contiguous()
+        self.ranks_depth = ranks_depth.int().contiguous()
+        self.interval_lengths = interval_lengths.int().contiguous()
+        starts = interval_starts.int().contiguous()
+        tag = getattr(interval_starts, '_veon_sorted', None)
+        if tag is not None:
+            starts._veon_sorted = tag
+        self.interval_starts = starts
+        B = coor.shape[0]
+        vpb = int(self.grid_size[2]) * int(self.grid_size[1]) * \
+            int(self.grid_size[0])
+        _bp.build_tile_table(self.ranks_bev, self.interval_starts, B, vpb,
+                             self.out_channels)
+
+    def _bev_feat_shape(self, B, C):
+        return (B, int(self.grid_size[2]), int(self.grid_size[1]),
+                int(self.grid_size[0]), C)  # (B, Z, Y, X, C)
+
+    def voxel_pooling_v2(self, coor, depth, feat):
+        """view_transformer_raw.py:217-242."""
+        ranks_bev, ranks_depth, ranks_feat, interval_starts, interval_lengths \
+            = self.voxel_pooling_prepare_v2(coor)
+        if ranks_feat is None:
+            print('warning ---> no points within the predefined '
+                  'bev receptive field')
+            # the reference's dummy, including its (Z, X, Y) axis order (:224-231)
+            dummy = torch.zeros(size=[
+                feat.shape[0], feat.shape[2], int(self.grid_size[2]),
+                int(self.grid_size[0]), int(self.grid_size[1])]).to(feat)
+            return torch.cat(dummy.unbind(dim=2), 1)
+        feat = feat.permute(0, 1, 3, 4, 2)
+        bev_feat = bev_pool_v2(
+            depth, feat, ranks_depth, ranks_feat, ranks_bev,
+            self._bev_feat_shape(depth.shape[0], feat.shape[-1]),
+            interval_starts, interval_lengths)
+        if self.collapse_z:
+            bev_feat = torch.cat(bev_feat.unbind(dim=2), 1)
+        return bev_feat
+
+    # ---------------------------------------------------------- entry points
+    def pre_compute(self, input):
+        if self.initial_flag:
+            coor = self.get_lidar_coor(*input[1:7])
+            self.init_acceleration_v2(coor)
+            self.initial_flag = False
+
+    def view_transform_core(self, input, depth, tran_feat):
+        B, N, C, H, W = input[0].shape
+        if self.accelerate:
+            feat = tran_feat.view(B, N, self.out_channels, H, W)
+            feat = feat.permute(0, 1, 3, 4, 2)
+            depth = depth.view(B, N, self.D, H, W)
+            bev_feat = bev_pool_v2(
+                depth, feat, self.ranks_depth, self.ranks_feat, self.ranks_bev,
+                self._bev_feat_shape(B, feat.shape[-1]), self.interval_starts,
+                self.interval_lengths)
+            bev_feat = bev_feat.squeeze(2)
+        else:
+            coor = self.get_lidar_coor(*input[1:7])
+            bev_feat = self.voxel_pooling_v2(
+                coor, depth.view(B, N, self.D, H, W),
+                tran_feat.view(B, N, self.out_channels, H, W))
+        if self._core_returns_depth:
+            return bev_feat, depth
+        return bev_feat
+
+    def view_transform(self, input, depth, tran_feat):
+        if self.accelerate:
+            self.pre_compute(input)
+        return self.view_transform_core(input, depth, tran_feat)

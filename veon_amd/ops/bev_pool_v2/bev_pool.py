@@ -1,0 +1,235 @@
+"""BEVPoolv2 op -- host-side mirror of mmdet3d/ops/bev_pool_v2/bev_pool.py.
+
+Same public names, argument order and return layout as the reference:
+
+    bev_pool_v2(depth[B,N,D,H,W], feat[B,N,H,W,C], ranks_depth[P], ranks_feat[P],
+                ranks_bev[P], bev_feat_shape=(B,Z,Y,X,C), interval_starts[I],
+                interval_lengths[I]) -> Tensor[B,C,Z,Y,X]   (bev_pool.py:86-92)
+    QuickCumsumCuda  (autograd.Function, bev_pool.py:11-83)
+    TRTBEVPoolv2     (ONNX symbolic + eager forward, bev_pool.py:95-142)
+
+What differs is underneath: the reference makes three full passes over the
+voxel volume (new_zeros :27, kernel store, permute().contiguous() :91); here a
+single fused HIP kernel writes the final (B,C,Z,Y,X) tensor once.  The fused
+kernel needs the intervals ascending in voxel rank -- what
+voxel_pooling_prepare_v2 always produces; for hand-made inputs that are not
+sorted the op falls back to the reference's three-pass structure (still HIP).
+There is no CPU path.
+"""
+import torch
+
+from ... import _lib
+from . import bev_pool_v2_ext
+
+__all__ = ['bev_pool_v2', 'TRTBEVPoolv2', 'QuickCumsumCuda']
+
+
+def mark_sorted(interval_starts, first_rank, last_rank):
+    """Tag produced-by-prepare interval arrays so the op never has to sync."""
+    interval_starts._veon_sorted = (True, int(first_rank), int(last_rank))
+    return interval_starts
+
+
+def _sorted_info(ranks_bev, interval_starts):
+    """(sorted?, first_rank, last_rank) of the interval keys.  Cached on the
+    tensor object; computing it costs one host sync, once per tensor."""
+    tag = getattr(interval_starts, '_veon_sorted', None)
+    if tag is None:
+        if interval_starts.numel() == 0:
+            tag = (True, 0, -1)
+        else:
+            keys = ranks_bev[interval_starts.long()]
+            ok = True
+            if keys.numel() > 1:
+                ok = bool((keys[1:] > keys[:-1]).all().item())
+            tag = (ok, int(keys[0].item()), int(keys[-1].item()))
+        interval_starts._veon_sorted = tag
+    return tag
+
+
+def _can_fuse(ranks_bev, interval_starts, n_voxels):
+    ok, first, last = _sorted_info(ranks_bev, interval_starts)
+    return ok and first >= 0 and last < n_voxels
+
+
+def _prep_inputs(depth, feat, ranks_depth, ranks_feat, ranks_bev,
+                 interval_starts, interval_lengths):
+    # casts of bev_pool.py:19-25 (no-ops for what the prepare produces)
+    tag = getattr(interval_starts, '_veon_sorted', None)
+    tiles = getattr(interval_starts, '_veon_tile_first', None)
+    depth = depth.contiguous().float()
+    feat = feat.contiguous().float()
+    ranks_bev = ranks_bev.contiguous().int()
+    ranks_depth = ranks_depth.contiguous().int()
+    ranks_feat = ranks_feat.contiguous().int()
+    interval_lengths = interval_lengths.contiguous().int()
+    interval_starts = interval_starts.contiguous().int()
+    if tag is not None:
+        interval_starts._veon_sorted = tag
+    if tiles is not None:
+        interval_starts._veon_tile_first = tiles
+    return (depth, feat, ranks_depth, ranks_feat, ranks_bev, interval_starts,
+            interval_lengths)
+
+
+def build_tile_table(ranks_bev, interval_starts, batch, voxels_per_batch,
+                     channels=0, layout=_lib.LAYOUT_BCZYX):
+    """Optional per-tile first-interval table for the fused kernels; cache it
+    with the ranks (accelerate=True).  Attached to ``interval_starts``."""
+    dev = _lib.require_device(ranks_bev, interval_starts)
+    L = _lib.lib()
+    v = L.veon_bev_pool_tile_voxels(channels, layout)
+    n_tiles = batch * ((voxels_per_batch + v - 1) // v)
+    table = torch.empty(n_tiles + 1, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        st = L.veon_bev_pool_tile_table(
+            interval_starts.numel(), batch, voxels_per_batch, v,
+            _lib.ptr(ranks_bev), _lib.ptr(interval_starts), _lib.ptr(table),
+            _lib.stream_ptr(dev))
+    _lib.check(st, 'veon_bev_pool_tile_table')
+    interval_starts._veon_tile_first = table
+    return table
+
+
+def _fused_forward(depth, feat, ranks_depth, ranks_feat, ranks_bev,
+                   interval_starts, interval_lengths, bev_feat_shape, layout):
+    B, Z, Y, X, C = [int(s) for s in bev_feat_shape]
+    dev = _lib.require_device(depth, feat, ranks_depth, ranks_feat, ranks_bev,
+                              interval_starts, interval_lengths)
+    if layout == _lib.LAYOUT_BCZYX:
+        out = torch.empty((B, C, Z, Y, X), dtype=torch.float32, device=dev)
+    else:
+        out = torch.empty((B, Z, Y, X, C), dtype=torch.float32, device=dev)
+    tiles = getattr(interval_starts, '_veon_tile_first', None)
+    with torch.cuda.device(dev):
+        st = _lib.lib().veon_bev_pool_v2_fwd_fused(
+            C, interval_starts.numel(), B, Z * Y * X, _lib.ptr(depth),
+            _lib.ptr(feat), _lib.ptr(ranks_depth), _lib.ptr(ranks_feat),
+            _lib.ptr(ranks_bev), _lib.ptr(interval_starts),
+            _lib.ptr(interval_lengths), _lib.ptr(tiles), _lib.ptr(out), layout,
+            _lib.stream_ptr(dev))
+    _lib.check(st, 'veon_bev_pool_v2_fwd_fused')
+    return out
+
+
+def _backward_impl(out_grad_bzyxc, ranks_bev, depth, feat, ranks_feat,
+                   ranks_depth):
+    """QuickCumsumCuda.backward, bev_pool.py:43-83: re-sort the points by
+    ranks_feat, rebuild intervals, launch the grad kernel."""
+    depth_grad = torch.zeros_like(depth)
+    feat_grad = torch.zeros_like(feat)
+    if ranks_feat.numel() == 0:
+        return depth_grad, feat_grad
+    # group the points by feature pixel (stable, so the order inside a group
+    # is the forward's storage order) and run-length encode the groups
+    rf_sorted, order = torch.sort(ranks_feat, stable=True)
+    _, counts = torch.unique_consecutive(rf_sorted, return_counts=True)
+    starts = torch.cumsum(counts, 0) - counts
+    bev_pool_v2_ext.bev_pool_v2_backward(
+        out_grad_bzyxc.contiguous(), depth_grad, feat_grad, depth, feat,
+        ranks_depth[order].contiguous(), rf_sorted.contiguous(),
+        ranks_bev[order].contiguous(), counts.int().contiguous(),
+        starts.int().contiguous())
+    return depth_grad, feat_grad
+
+
+class QuickCumsumCuda(torch.autograd.Function):
+    r"""BEVPoolv2 (`paper <https://arxiv.org/abs/2211.17111>`_); same contract
+    as the reference class (bev_pool.py:11-83): returns the channels-last
+    volume (B,Z,Y,X,C) and saves (ranks_bev, depth, feat, ranks_feat,
+    ranks_depth) for backward."""
+
+    @staticmethod
+    def forward(ctx, depth, feat, ranks_depth, ranks_feat, ranks_bev,
+                bev_feat_shape, interval_starts, interval_lengths):
+        (depth, feat, ranks_depth, ranks_feat, ranks_bev, interval_starts,
+         interval_lengths) = _prep_inputs(depth, feat, ranks_depth, ranks_feat,
+                                          ranks_bev, interval_starts,
+                                          interval_lengths)
+        B, Z, Y, X, C = [int(s) for s in bev_feat_shape]
+        if _can_fuse(ranks_bev, interval_starts, B * Z * Y * X):
+            out = _fused_forward(depth, feat, ranks_depth, ranks_feat,
+                                 ranks_bev, interval_starts, interval_lengths,
+                                 bev_feat_shape, _lib.LAYOUT_BZYXC)
+        else:
+            out = feat.new_zeros(tuple(int(s) for s in bev_feat_shape))
+            bev_pool_v2_ext.bev_pool_v2_forward(
+                depth, feat, out, ranks_depth, ranks_feat, ranks_bev,
+                interval_lengths, interval_starts)
+        ctx.save_for_backward(ranks_bev, depth, feat, ranks_feat, ranks_depth)
+        return out
+
+    @staticmethod
+    def backward(ctx, out_grad):
+        ranks_bev, depth, feat, ranks_feat, ranks_depth = ctx.saved_tensors
+        depth_grad, feat_grad = _backward_impl(out_grad, ranks_bev, depth,
+                                               feat, ranks_feat, ranks_depth)
+        return depth_grad, feat_grad, None, None, None, None, None, None
+
+
+class _BevPoolV2Fused(torch.autograd.Function):
+    """bev_pool_v2 with the permute of bev_pool.py:91 folded into the kernel:
+    returns (B,C,Z,Y,X) directly."""
+
+    @staticmethod
+    def forward(ctx, depth, feat, ranks_depth, ranks_feat, ranks_bev,
+                bev_feat_shape, interval_starts, interval_lengths):
+        out = _fused_forward(depth, feat, ranks_depth, ranks_feat, ranks_bev,
+                             interval_starts, interval_lengths, bev_feat_shape,
+                             _lib.LAYOUT_BCZYX)
+        ctx.save_for_backward(ranks_bev, depth, feat, ranks_feat, ranks_depth)
+        return out
+
+    @staticmethod
+    def backward(ctx, out_grad):
+        ranks_bev, depth, feat, ranks_feat, ranks_depth = ctx.saved_tensors
+        og = out_grad.permute(0, 2, 3, 4, 1).contiguous()
+        depth_grad, feat_grad = _backward_impl(og, ranks_bev, depth, feat,
+                                               ranks_feat, ranks_depth)
+        return depth_grad, feat_grad, None, None, None, None, None, None
+
+
+def bev_pool_v2(depth, feat, ranks_depth, ranks_feat, ranks_bev,
+                bev_feat_shape, interval_starts, interval_lengths):
+    """Drop-in for mmdet3d.ops.bev_pool_v2.bev_pool.bev_pool_v2
+    (bev_pool.py:86-92): returns the (B,C,Z,Y,X) contiguous fp32 volume,
+    differentiable w.r.t. depth and feat."""
+    (depth, feat, ranks_depth, ranks_feat, ranks_bev, interval_starts,
+     interval_lengths) = _prep_inputs(depth, feat, ranks_depth, ranks_feat,
+                                      ranks_bev, interval_starts,
+                                      interval_lengths)
+    B, Z, Y, X, C = [int(s) for s in bev_feat_shape]
+    if _can_fuse(ranks_bev, interval_starts, B * Z * Y * X):
+        return _BevPoolV2Fused.apply(depth, feat, ranks_depth, ranks_feat,
+                                     ranks_bev, bev_feat_shape,
+                                     interval_starts, interval_lengths)
+    x = QuickCumsumCuda.apply(depth, feat, ranks_depth, ranks_feat, ranks_bev,
+                              bev_feat_shape, interval_starts,
+                              interval_lengths)
+    return x.permute(0, 4, 1, 2, 3).contiguous()
+
+
+class TRTBEVPoolv2(torch.autograd.Function):
+    """ONNX export shim, same symbolic as the reference (bev_pool.py:95-142)."""
+
+    @staticmethod
+    def symbolic(g, depth, feat, ranks_depth, ranks_feat, ranks_bev,
+                 interval_starts, interval_lengths, out_height=128,
+                 out_width=128):
+        return g.op('mmdeploy::bev_pool_v2', depth, feat, ranks_depth,
+                    ranks_feat, ranks_bev, interval_starts, interval_lengths,
+                    out_height_i=out_height, out_width_i=out_width)
+
+    @staticmethod
+    def forward(g, depth, feat, ranks_depth, ranks_feat, ranks_bev,
+                interval_starts, interval_lengths, out_height=128,
+                out_width=128):
+        # depth (N,D,H,W), feat (N,H,W,C) -> (1, out_h, out_w, C)
+        feat = feat.unsqueeze(0)
+        depth = depth.unsqueeze(0)
+        bev_feat_shape = (depth.shape[0], 1, out_height, out_width,
+                          feat.shape[-1])
+        bev_feat = bev_pool_v2(depth, feat, ranks_depth, ranks_feat, ranks_bev,
+                               bev_feat_shape, interval_starts,
+                               interval_lengths)
+        return bev_feat.squeeze(2).permute(0, 2, 3, 1)
