@@ -1,0 +1,254 @@
+#!/usr/bin/env python
+"""bench.py -- 6-camera lift (LSS view transform + bev_pool_v2) on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one synthetic 6-camera sample:
+``view_transformer.view_transform(input, depth, tran_feat)`` -- the region the
+reference's own benchmark times (tools/analysis_tools/benchmark_view_transformer.py:
+120-138), with pre-computed ranks (``accelerate=True``, that tool's default).
+Workload = BASELINE.json configs[1]: 6 cams, 256x704, D=59, C=80, 200x200x16
+voxels.  Inputs are resident in HBM before the timed region.  N>1: one process
+per GPU (torchrun), independent samples per rank, no data-path collective
+("weak" scaling); the wall time is the max over ranks.
+
+Rank 0 prints ONE JSON line with `roofline` (bev_pool_v2 fused kernel, HBM
+bound, algorithmic bytes / mean launch time from HIP events) and `cpu_baseline`
+(the pure-PyTorch index_add_ port of the same step on the host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+WORKLOADS = {
+    # tag: (grid key, input_size, n_cams, C, neck type)
+    'S2': ('GRID_S2', (256, 704), 6, 80, 'LSSViewTransformer'),
+    'SV': ('GRID_VEON', (512, 1408), 6, 256, 'LSSViewTransformerRaw'),
+    'S1': ('GRID_BEVDET', (256, 704), 1, 64, 'LSSViewTransformer'),
+}
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument('--gpus', type=int, default=1)
+    p.add_argument('--steps', type=int, default=200)
+    p.add_argument('--warmup', type=int, default=20)
+    p.add_argument('--workload', default='S2', choices=sorted(WORKLOADS))
+    p.add_argument('--no-graph', action='store_true',
+                   help='eager launches instead of a captured hipGraph')
+    p.add_argument('--no-cpu-baseline', action='store_true')
+    p.add_argument('--cpu-seconds', type=float, default=12.0)
+    p.add_argument('--pmc-traffic', type=float, default=None,
+                   help='HBM bytes per launch from a separate rocprofv3 --pmc '
+                        'run (profiles/), copied into roofline.traffic')
+    return p.parse_args()
+
+
+def algorithmic_bytes(n_cams, hf, wf, C, D, p_kept, n_intervals, n_vox, batch=1):
+    """feat once + depth once + 3 rank arrays + 2 interval arrays
+    + the output volume written once (zeros included), fp32/int32."""
+    return 4 * (batch * n_cams * hf * wf * C + batch * n_cams * D * hf * wf +
+                3 * p_kept + 2 * n_intervals + batch * n_vox * C)
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a ROCm device (no CPU fallback)')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world,
+                                device_id=dev)
+
+    from veon_amd import _lib, synthetic
+    from veon_amd.models import build_neck
+    from veon_amd.ops.bev_pool_v2 import bev_pool as bp
+    _lib.lib()  # fail loudly if the HIP library is missing
+
+    grid_key, input_size, n_cams, C, neck_type = WORKLOADS[args.workload]
+    grid = getattr(synthetic, grid_key)
+    cfg = dict(type=neck_type, grid_config=grid, input_size=input_size,
+               downsample=16, out_channels=C, accelerate=True, collapse_z=False)
+    if neck_type == 'LSSViewTransformer':
+        cfg['in_channels'] = 8  # depth_net is not on the timed path
+    else:
+        cfg['ds_feat'] = [1, 1, 1]
+    vt = build_neck(cfg).to(dev).eval()
+    hf, wf = input_size[0] // 16, input_size[1] // 16
+    D = vt.D
+    rig = synthetic.make_rig(1, n_cams, input_size)
+    geom = [t.to(dev) for t in synthetic.rig_inputs(rig)]
+    depth5, feat5 = synthetic.make_depth_feat(1, n_cams, D, C, hf, wf,
+                                              seed=rank, device=dev)
+    depth = depth5.view(n_cams, D, hf, wf)
+    tran_feat = feat5.view(n_cams, C, hf, wf)
+    inp = [feat5] + geom
+    core_returns_tuple = vt._core_returns_depth
+
+    def step():
+        out = vt.view_transform(inp, depth, tran_feat)
+        return out[0] if core_returns_tuple else out
+
+    with torch.no_grad():
+        out = step()  # pre_compute + first launch
+        torch.cuda.synchronize()
+        Z, Y, X = (int(vt.grid_size[i]) for i in (2, 1, 0))
+        assert out.shape == (1, C, Z, Y, X), out.shape
+        p_kept = vt.ranks_bev.numel()
+        n_int = vt.interval_starts.numel()
+
+        graph = None
+        if not args.no_graph:
+            try:
+                s = torch.cuda.Stream()
+                s.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(s):
+                    for _ in range(3):
+                        step()
+                torch.cuda.current_stream().wait_stream(s)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    gout = step()
+            except Exception as e:  # report, do not hide
+                print('hipGraph capture failed (%s); running eager' % e,
+                      file=sys.stderr)
+                graph = None
+        run = graph.replay if graph is not None else step
+
+        for _ in range(args.warmup):
+            run()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            run()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        if dist is not None:
+            tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            elapsed = float(tmax.item())
+
+        # ---- kernel leg: the fused pool kernel alone, HIP events on the
+        # stream it is launched on (torch's current stream)
+        feat_nhwc = feat5.permute(0, 1, 3, 4, 2).contiguous()
+        shape = (1, Z, Y, X, C)
+
+        def kernel_only():
+            return bp._fused_forward(depth5, feat_nhwc, vt.ranks_depth,
+                                     vt.ranks_feat, vt.ranks_bev,
+                                     vt.interval_starts, vt.interval_lengths,
+                                     shape, _lib.LAYOUT_BCZYX)
+        for _ in range(10):
+            kernel_only()
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(args.steps):
+            kernel_only()
+        e1.record()
+        torch.cuda.synchronize()
+        kernel_ms = e0.elapsed_time(e1) / args.steps
+
+    alg = algorithmic_bytes(n_cams, hf, wf, C, D, p_kept, n_int, Z * Y * X)
+    achieved = alg / (kernel_ms * 1e-3) / 1e9
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * args.steps / elapsed
+
+    result = {
+        'metric': '6cam_lift_samples_per_sec',
+        'value': round(value, 2),
+        'unit': 'samples/s',
+        'n_gpus': world,
+        'steps': args.steps,
+        'warmup': args.warmup,
+        'ms_per_step': round(ms_per_step, 5),
+        'higher_is_better': True,
+        'scaling': 'weak',
+        'vs_baseline': None,
+        'dtype': 'f32',
+        'data': 'synthetic',
+        'config': {
+            'workload': '%s: %d-cam %dx%d, D=%d, C=%d, %dx%dx%d voxels, '
+                        'view_transform(accelerate=True) -> (B,C,Z,Y,X)'
+                        % (args.workload, n_cams, input_size[0], input_size[1],
+                           D, C, X, Y, Z),
+            'points_kept': p_kept, 'intervals': n_int,
+            'launch': 'hipGraph' if graph is not None else 'eager',
+            'parallelism': 'replicas x%d (one sample per GPU, no collective)' % world,
+        },
+        'roofline': {
+            'kernel': 'k_pool_fused_cf (bev_pool_v2 fused zero-fill+pool+layout)',
+            'bound': 'hbm',
+            'achieved': round(achieved, 1),
+            'peak': HBM_PEAK_GBS,
+            'unit': 'GB/s',
+            'frac': round(achieved / HBM_PEAK_GBS, 4),
+            'traffic': args.pmc_traffic,
+            'algorithmic_bytes': alg,
+            'kernel_ms': round(kernel_ms, 5),
+        },
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result['cpu_baseline'] = cpu_baseline(args, grid, input_size, n_cams, C,
+                                              rig, depth5, feat5)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, grid, input_size, n_cams, C, rig, depth5, feat5):
+    """The same step (pool with cached ranks -> (B,C,Z,Y,X)) by the pure-PyTorch
+    index_add_ port on the host cores.  The oracle is only the thing timed
+    here, never part of the product path."""
+    from oracle import lss_torch
+    threads = torch.get_num_threads()
+    lower, interval, gsize = lss_torch.grid_infos(grid)
+    fr = lss_torch.make_frustum(grid['depth'], input_size, 16)
+    cams = (rig['sensor2ego'], rig['intrins'], rig['post_rots'],
+            rig['post_trans'], rig['bda'])
+    coor = lss_torch.lidar_coor(fr, *cams)
+    ranks = lss_torch.voxel_prepare(coor, lower, interval, gsize)
+    d, f = depth5.cpu(), feat5.cpu()
+    for _ in range(2):
+        lss_torch.lift(fr, (lower, interval, gsize), cams, d, f, ranks=ranks)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        lss_torch.lift(fr, (lower, interval, gsize), cams, d, f, ranks=ranks)
+        n += 1
+        el = time.perf_counter() - t0
+        if el > args.cpu_seconds or n >= 200:
+            break
+    return {
+        'value': round(n / el, 3), 'unit': 'samples/s', 'cores': threads,
+        'kind': 'port',
+        'sample': '%d iterations (%.1f s) of oracle.lss_torch.lift with cached '
+                  'ranks on the %s workload, torch %d threads, fp32'
+                  % (n, el, args.workload, threads),
+    }
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,252 @@
+"""GPU parity of the HIP bev_pool_v2 kernels against the CPU oracle.
+
+Every call goes through the C ABI of libveon_hip.so (via the op mirror).
+Forward sums are serial fmaf chains in storage order on both sides, so the
+comparison is BIT-EXACT (np.array_equal), not tolerance-based.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import c_oracle
+from tests import helpers
+from tests.conftest import load_golden
+from veon_amd import _lib, synthetic
+from veon_amd.ops.bev_pool_v2 import bev_pool as bp
+from veon_amd.ops.bev_pool_v2 import bev_pool_v2_ext as ext
+from veon_amd.ops.bev_pool_v2.bev_pool import (QuickCumsumCuda, TRTBEVPoolv2,
+                                               bev_pool_v2)
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def dev(a):
+    return helpers.t(a, DEV)
+
+
+def _case_from_golden(name):
+    g = load_golden(name)
+    B, C = g['feat'].shape[0], g['feat'].shape[2]
+    X, Y, Z = (int(v) for v in g['grid_size'])
+    feat_nhwc = np.ascontiguousarray(g['feat'].transpose(0, 1, 3, 4, 2))
+    ranks = tuple(g[k] for k in ('ranks_bev', 'ranks_depth', 'ranks_feat',
+                                 'interval_starts', 'interval_lengths'))
+    return g['two_hot'], feat_nhwc, ranks, (B, Z, Y, X, C)
+
+
+def _synthetic_case(grid, input_size, n_cams, C, batch=1, seed=0):
+    ranks, coor, rig, fr, gsize = helpers.oracle_ranks(grid, input_size,
+                                                       n_cams, batch)
+    D = fr.shape[0]
+    hf, wf = input_size[0] // 16, input_size[1] // 16
+    depth, feat = synthetic.make_depth_feat(batch, n_cams, D, C, hf, wf, seed)
+    feat_nhwc = feat.permute(0, 1, 3, 4, 2).contiguous().numpy()
+    shape = (batch, int(gsize[2]), int(gsize[1]), int(gsize[0]), C)
+    return depth.numpy(), feat_nhwc, ranks, shape
+
+
+def _oracle_out(depth, feat_nhwc, ranks, shape):
+    rb, rd, rf, st, ln = ranks
+    B, Z, Y, X, C = shape
+    return c_oracle.bev_pool_v2_fwd(depth, feat_nhwc, rd, rf, rb, st, ln,
+                                    B * Z * Y * X).reshape(B, Z, Y, X, C)
+
+
+def _run_scatter(depth, feat_nhwc, ranks, shape):
+    rb, rd, rf, st, ln = (dev(a) for a in ranks)
+    out = torch.zeros(shape, dtype=torch.float32, device=DEV)
+    ext.bev_pool_v2_forward(dev(depth), dev(feat_nhwc), out, rd, rf, rb, ln, st)
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
+
+
+def _run_fused(depth, feat_nhwc, ranks, shape, layout, table=False):
+    rb, rd, rf, st, ln = (dev(a) for a in ranks)
+    if table:
+        B, Z, Y, X, C = shape
+        bp.build_tile_table(rb, st, B, Z * Y * X, C)
+    # poison the allocator so "every element written once" is actually tested
+    junk = torch.full((int(np.prod(shape)),), float('nan'), device=DEV)
+    del junk
+    out = bp._fused_forward(dev(depth), dev(feat_nhwc), rd, rf, rb, st, ln,
+                            shape, layout)
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
+
+
+def test_library_loaded_and_abi():
+    L = _lib.lib()
+    assert L.veon_abi_version() == 1
+    assert L.veon_status_string(0) == b'ok'
+
+
+def test_kat_forward_backward_through_op():
+    """The reference's own KAT (bev_pool.py:145-176), on the HIP path."""
+    g = load_golden('kat_bev_pool_v2')
+    depth = dev(g['depth']).requires_grad_()
+    feat = dev(g['feat']).requires_grad_()
+    out = bev_pool_v2(depth, feat, dev(g['ranks_depth']), dev(g['ranks_feat']),
+                      dev(g['ranks_bev']), tuple(int(v) for v in g['bev_feat_shape']),
+                      dev(g['interval_starts']), dev(g['interval_lengths']))
+    assert out.shape == (1, 2, 1, 2, 2) and out.is_contiguous()
+    loss = out.sum()
+    loss.backward()
+    assert loss.item() == pytest.approx(4.4, abs=1e-6)
+    assert np.float32(loss.item()) == g['expect_sum']
+    assert torch.allclose(depth.grad.cpu(), torch.from_numpy(g['expect_depth_grad']))
+    assert torch.allclose(feat.grad.cpu(), torch.from_numpy(g['expect_feat_grad']))
+
+
+@pytest.mark.parametrize('name', ['lss_small', 'lss_small_b2', 'lss_mid'])
+def test_scatter_and_fused_bit_exact_small(name):
+    depth, feat_nhwc, ranks, shape = _case_from_golden(name)
+    want = _oracle_out(depth, feat_nhwc, ranks, shape)
+    assert np.array_equal(_run_scatter(depth, feat_nhwc, ranks, shape), want)
+    for table in (False, True):
+        got = _run_fused(depth, feat_nhwc, ranks, shape, _lib.LAYOUT_BZYXC, table)
+        assert np.array_equal(got, want)
+        got = _run_fused(depth, feat_nhwc, ranks, shape, _lib.LAYOUT_BCZYX, table)
+        assert np.array_equal(got, want.transpose(0, 4, 1, 2, 3))
+
+
+@pytest.mark.parametrize('grid,size,cams,C', [
+    (synthetic.GRID_BEVDET, (256, 704), 1, 64),    # BASELINE configs[0]
+    (synthetic.GRID_S2, (256, 704), 6, 80),        # BASELINE configs[1]
+])
+def test_full_size_bit_exact(grid, size, cams, C):
+    depth, feat_nhwc, ranks, shape = _synthetic_case(grid, size, cams, C)
+    want = _oracle_out(depth, feat_nhwc, ranks, shape)
+    assert np.array_equal(_run_scatter(depth, feat_nhwc, ranks, shape), want)
+    assert np.array_equal(
+        _run_fused(depth, feat_nhwc, ranks, shape, _lib.LAYOUT_BZYXC), want)
+    assert np.array_equal(
+        _run_fused(depth, feat_nhwc, ranks, shape, _lib.LAYOUT_BCZYX, True),
+        want.transpose(0, 4, 1, 2, 3))
+
+
+def test_veon_shape_c256_bit_exact():
+    """SV: 6 cams 512x1408, D=88, C=256 (655 MB volume), channel slabs."""
+    depth, feat_nhwc, ranks, shape = _synthetic_case(
+        synthetic.GRID_VEON, (512, 1408), 6, 256)
+    want = _oracle_out(depth, feat_nhwc, ranks, shape)
+    got = _run_fused(depth, feat_nhwc, ranks, shape, _lib.LAYOUT_BCZYX)
+    assert np.array_equal(got, want.transpose(0, 4, 1, 2, 3))
+    del got
+    got = _run_fused(depth, feat_nhwc, ranks, shape, _lib.LAYOUT_BZYXC)
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize('C', [1, 3, 7, 80, 130])
+def test_odd_channel_counts_and_ragged_tiles(C):
+    """Scalar path (C % 4 != 0), slab path (C > 128) and a voxel count that is
+    not a multiple of the tile (5*7*3 = 105 voxels)."""
+    rng = np.random.default_rng(C)
+    B, Z, Y, X = 2, 3, 7, 5
+    nvox = B * Z * Y * X
+    n_pts, n_feat, n_depth = 400, 30, 500
+    rb = np.sort(rng.integers(0, nvox, n_pts)).astype(np.int32)
+    rd = rng.integers(0, n_depth, n_pts).astype(np.int32)
+    rf = rng.integers(0, n_feat, n_pts).astype(np.int32)
+    st, ln = helpers.bp_intervals(rb)
+    depth = rng.random((1, 1, n_depth, 1, 1), dtype=np.float32)
+    feat = rng.standard_normal((1, 1, n_feat, 1, C)).astype(np.float32)
+    shape = (B, Z, Y, X, C)
+    ranks = (rb, rd, rf, st, ln)
+    want = _oracle_out(depth, feat, ranks, shape)
+    assert np.array_equal(_run_scatter(depth, feat, ranks, shape), want)
+    assert np.array_equal(_run_fused(depth, feat, ranks, shape, _lib.LAYOUT_BZYXC), want)
+    assert np.array_equal(_run_fused(depth, feat, ranks, shape, _lib.LAYOUT_BCZYX),
+                          want.transpose(0, 4, 1, 2, 3))
+
+
+def test_empty_and_single_interval():
+    shape = (1, 2, 3, 4, 8)
+    depth = np.ones((1, 1, 4, 1, 1), np.float32)
+    feat = np.ones((1, 1, 2, 1, 8), np.float32)
+    empty = tuple(np.zeros(0, np.int32) for _ in range(5))
+    for layout in (_lib.LAYOUT_BZYXC, _lib.LAYOUT_BCZYX):
+        assert not _run_fused(depth, feat, empty, shape, layout).any()
+    one = (np.array([23], np.int32), np.array([1], np.int32),
+           np.array([0], np.int32), np.array([0], np.int32),
+           np.array([1], np.int32))
+    got = _run_fused(depth, feat, one, shape, _lib.LAYOUT_BZYXC).reshape(24, 8)
+    assert (got[23] == 1).all() and not got[:23].any()
+
+
+def test_unsorted_intervals_take_reference_structure():
+    """Hand-made inputs whose intervals are not ascending cannot use the fused
+    kernel; the op must still return the reference's result."""
+    depth, feat_nhwc, ranks, shape = _case_from_golden('lss_small')
+    rb, rd, rf, st, ln = ranks
+    perm = np.random.default_rng(0).permutation(len(st))
+    # rebuild the point arrays interval by interval in shuffled order
+    segs = [np.arange(st[i], st[i] + ln[i]) for i in perm]
+    order = np.concatenate(segs)
+    rb2, rd2, rf2 = rb[order], rd[order], rf[order]
+    ln2 = ln[perm]
+    st2 = (np.cumsum(ln2) - ln2).astype(np.int32)
+    out = bev_pool_v2(dev(depth), dev(feat_nhwc), dev(rd2), dev(rf2), dev(rb2),
+                      shape, dev(st2), dev(ln2))
+    want = _oracle_out(depth, feat_nhwc, ranks, shape).transpose(0, 4, 1, 2, 3)
+    assert np.array_equal(out.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize('name', ['lss_small_b2', 'lss_mid'])
+def test_backward_bit_exact(name):
+    depth, feat_nhwc, ranks, shape = _case_from_golden(name)
+    rb, rd, rf, st, ln = ranks
+    rng = np.random.default_rng(1)
+    og = rng.standard_normal(shape).astype(np.float32)
+    want_dg, want_fg = helpers.oracle_backward(og, depth, feat_nhwc, rd, rf, rb)
+    d = dev(depth).requires_grad_()
+    f = dev(feat_nhwc).requires_grad_()
+    out = QuickCumsumCuda.apply(d, f, dev(rd), dev(rf), dev(rb), shape,
+                                dev(st), dev(ln))
+    assert out.shape == shape
+    out.backward(dev(og))
+    assert np.array_equal(d.grad.cpu().numpy(), want_dg)
+    assert np.array_equal(f.grad.cpu().numpy(), want_fg)
+    # and through the channels-first op (out_grad arrives as (B,C,Z,Y,X))
+    d2 = dev(depth).requires_grad_()
+    f2 = dev(feat_nhwc).requires_grad_()
+    out2 = bev_pool_v2(d2, f2, dev(rd), dev(rf), dev(rb), shape, dev(st), dev(ln))
+    out2.backward(dev(og.transpose(0, 4, 1, 2, 3)))
+    assert np.array_equal(d2.grad.cpu().numpy(), want_dg)
+    assert np.array_equal(f2.grad.cpu().numpy(), want_fg)
+
+
+def test_trt_shim_eager_forward():
+    depth, feat_nhwc, ranks, shape = _synthetic_case(
+        synthetic.GRID_BEVDET, (256, 704), 1, 64)
+    rb, rd, rf, st, ln = ranks
+    out = TRTBEVPoolv2.apply(dev(depth[0]), dev(feat_nhwc[0]), dev(rd), dev(rf),
+                             dev(rb), dev(st), dev(ln), 128, 128)
+    want = _oracle_out(depth, feat_nhwc, ranks, shape)[:, 0]
+    assert out.shape == (1, 128, 128, 64)
+    assert np.array_equal(out.cpu().numpy(), want)
+
+
+def test_size_independent_properties_full_size():
+    """At BASELINE size: linearity in depth, and mass conservation
+    sum(out) == sum_p depth*sum_c feat (fp64 reference)."""
+    depth, feat_nhwc, ranks, shape = _synthetic_case(
+        synthetic.GRID_S2, (256, 704), 6, 80)
+    rb, rd, rf, st, ln = ranks
+    a = _run_fused(depth, feat_nhwc, ranks, shape, _lib.LAYOUT_BCZYX)
+    b = _run_fused(depth * np.float32(2.0), feat_nhwc, ranks, shape,
+                   _lib.LAYOUT_BCZYX)
+    assert np.array_equal(b, a * np.float32(2.0))     # exact: power of two
+    mass = (depth.reshape(-1)[rd].astype(np.float64) *
+            feat_nhwc.reshape(-1, shape[-1])[rf].astype(np.float64).sum(1)).sum()
+    assert a.astype(np.float64).sum() == pytest.approx(mass, rel=1e-6, abs=1e-3)
+    # untouched voxels are exactly zero
+    occ = np.zeros(np.prod(shape[:4]), bool)
+    occ[rb] = True
+    assert not a.reshape(shape[0], shape[4], -1)[0][:, ~occ[:a[0, 0].size]].any()
+
+
+def test_cpu_tensors_raise():
+    with pytest.raises(_lib.VeonHipError):
+        ext.bev_pool_v2_forward(*(torch.zeros(1),) * 3,
+                                *(torch.zeros(1, dtype=torch.int32),) * 5)

@@ -1,0 +1,174 @@
+"""CPU-side checks: the C-ABI library loads and exports every declared symbol,
+the plugin surface has the reference's names, and the device-agnostic host
+logic (geometry / prepare / depth prep in torch ops) reproduces the golden
+vectors.  No compute call reaches the HIP library here (no GPU)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from tests.conftest import ROOT, load_golden
+from veon_amd import _lib, depth_ops, lss_prepare, synthetic
+from veon_amd.models import NECKS, build_neck
+from veon_amd.models.necks import (LSSViewTransformer,
+                                   LSSViewTransformerBEVDepth,
+                                   LSSViewTransformerBEVStereo,
+                                   LSSViewTransformerRaw)
+from veon_amd.ops.bev_pool_v2 import (QuickCumsumCuda, TRTBEVPoolv2,
+                                      bev_pool_v2)
+from veon_amd.ops.bev_pool_v2 import bev_pool_v2_ext
+
+
+def _header_symbols():
+    names = set()
+    inc = os.path.join(ROOT, 'include')
+    for fn in os.listdir(inc):
+        if fn.endswith('.h'):
+            src = open(os.path.join(inc, fn)).read()
+            src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+            names |= set(re.findall(r'\b(veon_[a-z0-9_]+)\s*\(', src))
+    return names
+
+
+def test_library_exports_every_declared_symbol():
+    from veon_amd import build
+    build.build()
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    declared = _header_symbols()
+    assert declared, 'no declarations found in include/*.h'
+    for name in declared:
+        assert hasattr(lib, name), 'libveon_hip.so lacks %s' % name
+    # the Python binding knows every declared entry point and nothing else
+    assert set(_lib.declared_symbols()) == declared
+    lib.veon_abi_version.restype = ctypes.c_int
+    assert lib.veon_abi_version() == 1          # host-only call, no GPU needed
+
+
+def test_ops_refuse_cpu_tensors():
+    z = torch.zeros(1)
+    i = torch.zeros(1, dtype=torch.int32)
+    with pytest.raises(_lib.VeonHipError):
+        bev_pool_v2_ext.bev_pool_v2_forward(z, z, z, i, i, i, i, i)
+    with pytest.raises(_lib.VeonHipError):
+        bev_pool_v2(torch.zeros(1, 1, 1, 1, 1), torch.zeros(1, 1, 1, 1, 1), i, i,
+                    i, (1, 1, 1, 1, 1), i, i)
+
+
+def test_ext_validates_dtypes():
+    z = torch.zeros(1)
+    i = torch.zeros(1, dtype=torch.int32)
+    with pytest.raises(TypeError):
+        bev_pool_v2_ext.bev_pool_v2_forward(z.double(), z, z, i, i, i, i, i)
+    with pytest.raises(TypeError):
+        bev_pool_v2_ext.bev_pool_v2_forward(z, z, z, i.long(), i, i, i, i)
+
+
+def test_plugin_surface_names():
+    for cls in (LSSViewTransformer, LSSViewTransformerBEVDepth,
+                LSSViewTransformerBEVStereo, LSSViewTransformerRaw):
+        assert NECKS.get(cls.__name__) is cls
+        for m in ('create_grid_infos', 'create_frustum', 'get_lidar_coor',
+                  'init_acceleration_v2', 'voxel_pooling_v2',
+                  'voxel_pooling_prepare_v2', 'pre_compute',
+                  'view_transform_core', 'view_transform', 'forward'):
+            assert callable(getattr(cls, m)), (cls, m)
+    for m in ('downsample_depth', 'get_two_hot_depth', 'get_one_hot_depth'):
+        assert callable(getattr(LSSViewTransformerRaw, m))
+    assert callable(bev_pool_v2) and issubclass(QuickCumsumCuda, torch.autograd.Function)
+    assert hasattr(TRTBEVPoolv2, 'symbolic')
+    with pytest.raises(KeyError):
+        build_neck(dict(type='NoSuchNeck'))
+
+
+def test_veon_config_builds_unchanged():
+    """The img_view_transformer dict of
+    configs/veon/veon-temporal-base-512x1408-dav2-nodepthcache.py:71-82."""
+    cfg = dict(type='LSSViewTransformerRaw', grid_config=synthetic.GRID_VEON,
+               input_size=(512, 1408), sid=False, collapse_z=False,
+               out_channels=256, downsample=16, mode='nuscenes',
+               loss_depth_weight=0.05, ds_feat=[2, 2, 2])
+    vt = build_neck(cfg)
+    assert vt.D == 88 and tuple(vt.frustum.shape) == (88, 32, 88, 3)
+    assert vt.grid_size.tolist() == [200.0, 200.0, 16.0]
+    assert vt.out_channels == 256 and vt.accelerate is False and vt.initial_flag
+    assert vt.mode == 'nuscenes' and vt.use_ds
+
+
+def test_bevdepth_builds_and_mlp_input():
+    vt = build_neck(dict(
+        type='LSSViewTransformerBEVDepth', grid_config=synthetic.GRID_BEVDET,
+        input_size=(256, 704), in_channels=16, out_channels=8,
+        depthnet_cfg=dict(use_dcn=False, aspp_mid_channels=8)))
+    assert vt.D == 59 and vt.grid_size.tolist() == [128.0, 128.0, 1.0]
+    rig = synthetic.make_rig(2, 6, (256, 704))
+    mlp = vt.get_mlp_input(*synthetic.rig_inputs(rig))
+    assert mlp.shape == (2, 6, 27)
+    assert torch.equal(mlp[0, 1, 15:], rig['sensor2ego'][0, 1, :3, :].reshape(-1))
+    assert mlp[0, 0, 0] == rig['intrins'][0, 0, 0, 0]
+
+
+@pytest.mark.parametrize('name', ['lss_small', 'lss_small_b2', 'lss_mid'])
+def test_host_prepare_reproduces_reference(name):
+    g = load_golden(name)
+    grid = {'x': list(g['grid_x']), 'y': list(g['grid_y']),
+            'z': list(g['grid_z']), 'depth': list(g['grid_depth'])}
+    vt = LSSViewTransformerRaw(grid_config=grid,
+                               input_size=tuple(int(v) for v in g['input_size']),
+                               out_channels=4, collapse_z=False)
+    assert np.array_equal(vt.frustum.numpy(), g['frustum'])
+    assert np.array_equal(vt.grid_lower_bound.numpy(), g['grid_lower_bound'])
+    assert np.array_equal(vt.grid_interval.numpy(), g['grid_interval'])
+    assert np.array_equal(vt.grid_size.numpy(), g['grid_size'])
+    inp = [torch.from_numpy(g[k]) for k in ('sensor2ego', 'ego2global', 'intrins',
+                                            'post_rots', 'post_trans', 'bda')]
+    coor = vt.get_lidar_coor(*inp)
+    assert np.array_equal(coor.numpy(), g['coor'])
+    out = vt.voxel_pooling_prepare_v2(coor)
+    for got, key in zip(out, ('ranks_bev', 'ranks_depth', 'ranks_feat',
+                              'interval_starts', 'interval_lengths')):
+        assert got.dtype == torch.int32 and got.is_contiguous()
+        assert np.array_equal(got.numpy(), g[key]), key
+    ds = vt.downsample_depth(torch.from_numpy(g['metric_depth']), 8)
+    assert np.array_equal(ds.numpy(), g['ds_depth'])
+    th = vt.get_two_hot_depth(ds)
+    assert th.shape == g['two_hot'].shape
+    np.testing.assert_allclose(th.numpy(), g['two_hot'], rtol=2e-6, atol=1e-9)
+    # downsample=True branch == explicit two-step
+    th2 = vt.get_two_hot_depth(torch.from_numpy(g['metric_depth'][:, :, ::1, ::1]),
+                               downsample=False)
+    assert th2.shape[2] == vt.D
+
+
+def test_prepare_returns_none_when_empty():
+    coor = torch.full((1, 1, 2, 2, 2, 3), 1e6)
+    lower, interval, size = (torch.tensor(v, dtype=torch.float32) for v in
+                             ([0, 0, 0], [1, 1, 1], [4, 4, 2]))
+    assert lss_prepare.voxel_pooling_prepare_v2(coor, lower, interval, size) == \
+        (None,) * 5
+
+
+def test_one_hot_depth_is_argmax_of_two_hot():
+    vt = LSSViewTransformerRaw(grid_config=synthetic.GRID_VEON,
+                               input_size=(64, 176), out_channels=4,
+                               collapse_z=False)
+    d = 1.0 + 43.0 * torch.rand(1, 2, 4, 11)
+    one = vt.get_one_hot_depth(d)
+    two = vt.get_two_hot_depth(d)
+    assert one.shape == two.shape == (1, 2, vt.D, 4, 11)
+    inside = one.sum(2) > 0
+    assert torch.equal(one.argmax(2)[inside], two.argmax(2)[inside])
+
+
+def test_synthetic_rig_is_deterministic_and_sane():
+    a = synthetic.make_rig(1, 6, (256, 704))
+    b = synthetic.make_rig(1, 6, (256, 704))
+    for k in a:
+        assert torch.equal(a[k], b[k])
+    r = a['sensor2ego'][0, :, :3, :3]
+    eye = torch.eye(3).expand(6, 3, 3)
+    assert torch.allclose(r @ r.transpose(1, 2), eye, atol=1e-6)
+    assert a['post_rots'][0, 0, 0, 0] == pytest.approx(0.44)
+    assert a['post_trans'][0, 0].tolist() == [0.0, -140.0, 0.0]

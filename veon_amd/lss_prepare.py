@@ -42,26 +42,36 @@ def _mat_vec(m, p):
     return acc
 
 
-def get_lidar_coor_torch(frustum, sensor2ego, cam2imgs, post_rots, post_trans,
-                         bda):
-    B, N = sensor2ego.shape[:2]
-    pri, comb, trans = camera_matrices(sensor2ego, cam2imgs, post_rots)
-    fr = frustum.to(sensor2ego)
+def lidar_coor_from_matrices_torch(frustum, post_rots_inv, post_trans, combine,
+                                   trans, bda):
+    B, N = combine.shape[:2]
+    fr = frustum.to(combine)
     p = fr.view(1, 1, *fr.shape) - post_trans.view(B, N, 1, 1, 1, 3)
-    p = _mat_vec(pri.view(B, N, 1, 1, 1, 3, 3), p)
+    p = _mat_vec(post_rots_inv.view(B, N, 1, 1, 1, 3, 3), p)
     p = torch.cat((p[..., :2] * p[..., 2:3], p[..., 2:3]), -1)
-    p = _mat_vec(comb.view(B, N, 1, 1, 1, 3, 3), p)
+    p = _mat_vec(combine.view(B, N, 1, 1, 1, 3, 3), p)
     p = p + trans.view(B, N, 1, 1, 1, 3)
     p = _mat_vec(bda.view(B, 1, 1, 1, 1, 3, 3), p)
     return p
 
 
+def lidar_coor_from_matrices(frustum, post_rots_inv, post_trans, combine, trans,
+                             bda):
+    """Per-point half of get_lidar_coor (:144-155) given the camera matrices.
+    Bit-identical to the reference's CPU result for identical matrices."""
+    if combine.is_cuda and _HIP_PREPARE is not None:
+        return _HIP_PREPARE.lidar_coor_from_matrices(
+            frustum, post_rots_inv, post_trans, combine, trans, bda)
+    return lidar_coor_from_matrices_torch(frustum, post_rots_inv, post_trans,
+                                          combine, trans, bda)
+
+
 def get_lidar_coor(frustum, sensor2ego, cam2imgs, post_rots, post_trans, bda):
-    if sensor2ego.is_cuda and _HIP_PREPARE is not None:
-        return _HIP_PREPARE.get_lidar_coor(frustum, sensor2ego, cam2imgs,
-                                           post_rots, post_trans, bda)
-    return get_lidar_coor_torch(frustum, sensor2ego, cam2imgs, post_rots,
-                                post_trans, bda)
+    """view_transformer_raw.py:121-158.  The two ``torch.inverse`` calls run on
+    the tensors' device exactly as in the reference (their last bits are
+    backend-dependent there too: LAPACK on CPU, rocSOLVER on a GPU)."""
+    pri, comb, trans = camera_matrices(sensor2ego, cam2imgs, post_rots)
+    return lidar_coor_from_matrices(frustum, pri, post_trans, comb, trans, bda)
 
 
 def voxel_pooling_prepare_v2_torch(coor, lower, interval, gsize):
