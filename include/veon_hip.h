@@ -69,41 +69,40 @@ int veon_bev_pool_v2_bwd(int c, int n_intervals, const float *out_grad,
                          float *feat_grad, void *stream);
 
 /*
+ * Pool plan for the fused forward.  The fused kernels walk the output in tiles
+ * of veon_bev_pool_tile_voxels() consecutive voxel ranks; plan entry t is
+ * {first interval, #intervals, first point, #points} of tile t.  `plan` must
+ * hold veon_bev_pool_plan_ints(batch, voxels_per_batch) int32 values, 16-byte
+ * aligned; the first 4*n_tiles are the entries, the rest is build scratch.
+ * Build it once beside the five rank arrays when they are cached (the
+ * accelerate=True path, view_transformer_raw.py:196-215), or per call
+ * (two tiny kernels).  Requires the intervals ascending and unique in
+ * ranks_bev[interval_starts[i]] -- what voxel_pooling_prepare_v2 produces
+ * (view_transformer_raw.py:287-299).
+ */
+int veon_bev_pool_tile_voxels(void);
+int64_t veon_bev_pool_plan_ints(int batch, int64_t voxels_per_batch);
+int veon_bev_pool_plan(int n_intervals, int n_points, int batch,
+                       int64_t voxels_per_batch, const int *ranks_bev,
+                       const int *interval_starts, int *plan, void *stream);
+
+/*
  * Fused forward: zero-fill + pool (+ layout permute) in ONE pass; every
  * element of `out` is written exactly once, so `out` may be uninitialised.
  * Replaces the three full-volume passes of the reference
  * (new_zeros bev_pool.py:27, kernel store bev_pool_cuda.cu:46-47,
- * permute().contiguous() bev_pool.py:91).
- *
- * Precondition (what voxel_pooling_prepare_v2 produces,
- * view_transformer_raw.py:287-299): intervals ascending and unique in
- * ranks_bev[interval_starts[i]], all < batch * voxels_per_batch.
- * `tile_first` is optional (NULL = search in-kernel): see
- * veon_bev_pool_tile_table().
+ * permute().contiguous() bev_pool.py:91).  Same summation as
+ * veon_bev_pool_v2_fwd (serial fmaf chain per interval), so the results are
+ * bit-identical to the three-pass structure.
+ * Preconditions: as veon_bev_pool_plan; all ranks < batch * voxels_per_batch.
  */
 int veon_bev_pool_v2_fwd_fused(int c, int n_intervals, int batch,
                                int64_t voxels_per_batch, const float *depth,
                                const float *feat, const int *ranks_depth,
                                const int *ranks_feat, const int *ranks_bev,
                                const int *interval_starts,
-                               const int *interval_lengths,
-                               const int *tile_first, float *out,
-                               int out_layout, void *stream);
-
-/* Voxels per tile the fused kernels use for `out_layout` and channel count
- * (tile t covers voxel ranks [t*V, (t+1)*V) of one batch element). */
-int veon_bev_pool_tile_voxels(int c, int out_layout);
-
-/*
- * Fill tile_first[0 .. n_tiles] (n_tiles = batch * ceil(voxels_per_batch / V))
- * with the index of the first interval whose voxel rank is >= the tile's first
- * rank (tile_first[n_tiles] = n_intervals).  Cache it beside the five rank
- * arrays (the accelerate=True path, view_transformer_raw.py:196-215).
- */
-int veon_bev_pool_tile_table(int n_intervals, int batch,
-                             int64_t voxels_per_batch, int tile_voxels,
-                             const int *ranks_bev, const int *interval_starts,
-                             int *tile_first, void *stream);
+                               const int *interval_lengths, const int *plan,
+                               float *out, int out_layout, void *stream);
 
 #ifdef __cplusplus
 }

@@ -62,10 +62,12 @@ def _run_scatter(depth, feat_nhwc, ranks, shape):
 
 
 def _run_fused(depth, feat_nhwc, ranks, shape, layout, table=False):
+    """table=True: plan cached on interval_starts (accelerate path);
+    False: plan rebuilt inside the call."""
     rb, rd, rf, st, ln = (dev(a) for a in ranks)
     if table:
         B, Z, Y, X, C = shape
-        bp.build_tile_table(rb, st, B, Z * Y * X, C)
+        bp.build_plan(rb, st, B, Z * Y * X)
     # poison the allocator so "every element written once" is actually tested
     junk = torch.full((int(np.prod(shape)),), float('nan'), device=DEV)
     del junk

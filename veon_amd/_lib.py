@@ -26,8 +26,9 @@ _SIGNATURES = {
     'veon_bev_pool_v2_fwd': (_ci, [_ci, _ci] + [_vp] * 8 + [_vp]),
     'veon_bev_pool_v2_bwd': (_ci, [_ci, _ci] + [_vp] * 10 + [_vp]),
     'veon_bev_pool_v2_fwd_fused': (_ci, [_ci, _ci, _ci, _i64] + [_vp] * 9 + [_ci, _vp]),
-    'veon_bev_pool_tile_voxels': (_ci, [_ci, _ci]),
-    'veon_bev_pool_tile_table': (_ci, [_ci, _ci, _i64, _ci, _vp, _vp, _vp, _vp]),
+    'veon_bev_pool_tile_voxels': (_ci, []),
+    'veon_bev_pool_plan_ints': (_i64, [_ci, _i64]),
+    'veon_bev_pool_plan': (_ci, [_ci, _ci, _ci, _i64, _vp, _vp, _vp, _vp]),
 }
 
 LAYOUT_BZYXC = 0

@@ -139,211 +139,289 @@ __global__ __launch_bounds__(kBlock) void k_pool_scatter(
 }
 
 // ---------------------------------------------------------------------------
-// Wave-wide 64-ary lower bound over the interval keys
-//   key(i) = ranks_bev[interval_starts[i]]   (ascending, unique)
-// Returns the first i in [0, n) with key(i) >= target (n if none).  All 64
-// lanes of the calling wave must be active; <= 4 rounds for n < 16.7 M.
+// Pool plan.  The fused kernels walk the output in tiles of kTileV = 64
+// consecutive voxel ranks of one batch element.  plan[t] = {i0, cnt, p0, npts}:
+// first interval / number of intervals / first point / number of points of
+// tile t (intervals are ascending in voxel rank, so a tile's intervals and
+// points are contiguous).  Built by two tiny kernels; cache it with the ranks
+// (accelerate=True) or let the prepare kernel emit it.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ int wave_lower_bound(const PoolArgs& a, int n,
-                                                int64_t target) {
-  const int lane = threadIdx.x & (kWave - 1);
-  int lo = 0, hi = n;
-  while (hi > lo) {
-    const int span = hi - lo;
-    const int step = (span + kWave - 1) / kWave;
-    const int64_t p = (int64_t)lo + (int64_t)lane * step;
-    bool below = false;
-    if (p < hi) below = (int64_t)a.ranks_bev[a.interval_starts[p]] < target;
-    const int cnt = __popcll(__ballot(below));
-    if (cnt == 0) {
-      hi = lo;
-    } else {
-      const int64_t last = (int64_t)lo + (int64_t)(cnt - 1) * step;
-      const int64_t nhi = last + step;
-      lo = (int)(last + 1);
-      hi = (int)(nhi < hi ? nhi : hi);
-    }
+constexpr int kTileV = 64;
+
+// one thread per interval (+1 sentinel): tiles (tile(i-1), tile(i)] start at i
+__global__ __launch_bounds__(kBlock) void k_plan_bounds(
+    const int* __restrict__ ranks_bev, const int* __restrict__ interval_starts,
+    int n_intervals, int n_points, int64_t vpb, int64_t tiles_per_batch,
+    int64_t n_tiles, int* __restrict__ tile_first, int* __restrict__ tile_point) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i > n_intervals) return;
+  auto tile_of = [&](int rank) -> int64_t {
+    const int64_t b = rank / vpb;
+    return b * tiles_per_batch + (rank - b * vpb) / kTileV;
+  };
+  int64_t hi = n_tiles;
+  int st = n_points;
+  if (i < n_intervals) {
+    st = interval_starts[i];
+    hi = tile_of(ranks_bev[st]);
   }
-  return lo;
+  const int64_t lo =
+      (i == 0) ? -1 : tile_of(ranks_bev[interval_starts[i - 1]]);
+  for (int64_t tt = lo + 1; tt <= hi; ++tt) {
+    tile_first[tt] = (int)i;
+    tile_point[tt] = st;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_plan_pack(
+    const int* __restrict__ tile_first, const int* __restrict__ tile_point,
+    int64_t n_tiles, int4* __restrict__ plan) {
+  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (t >= n_tiles) return;
+  plan[t] = make_int4(tile_first[t], tile_first[t + 1] - tile_first[t],
+                      tile_point[t], tile_point[t + 1] - tile_point[t]);
 }
 
 struct TileInfo {
-  int b;              // batch element
-  int64_t vox0;       // first voxel of the tile inside its batch element
-  int nvox;           // voxels in this tile (<= V)
-  int64_t rank0;      // b * voxels_per_batch + vox0
+  int b;          // batch element
+  int64_t vox0;   // first voxel of the tile inside its batch element
+  int nvox;       // voxels in this tile (<= kTileV)
+  int64_t rank0;  // b * voxels_per_batch + vox0
 };
 
 __device__ __forceinline__ TileInfo tile_info(int64_t t, int64_t tiles_per_batch,
-                                              int64_t vpb, int V) {
+                                              int64_t vpb) {
   TileInfo ti;
   ti.b = (int)(t / tiles_per_batch);
-  ti.vox0 = (t - (int64_t)ti.b * tiles_per_batch) * V;
+  ti.vox0 = (t - (int64_t)ti.b * tiles_per_batch) * kTileV;
   const int64_t rem = vpb - ti.vox0;
-  ti.nvox = (int)(rem < V ? rem : V);
+  ti.nvox = (int)(rem < kTileV ? rem : kTileV);
   ti.rank0 = (int64_t)ti.b * vpb + ti.vox0;
   return ti;
 }
 
-// Tile prologue shared by the fused kernels: find the first interval of the
-// tile (table or in-kernel search by wave 0) and fill slot[v] = interval index
-// of voxel v of the tile, or -1.  A tile holds <= V intervals (unique voxels),
-// and they are contiguous from i0, so one probe per thread suffices (V <= 256).
-template <int V>
-__device__ __forceinline__ void tile_slots(const PoolArgs& a, int n_intervals,
-                                           const int* __restrict__ tile_first,
-                                           int64_t t, const TileInfo& ti,
-                                           int* slot, int* s_i0) {
-  const int tid = threadIdx.x;
-  if (tile_first != nullptr) {
-    if (tid == 0) *s_i0 = tile_first[t];
-  } else if (tid < kWave) {
-    const int i0 = wave_lower_bound(a, n_intervals, ti.rank0);
-    if (tid == 0) *s_i0 = i0;
-  }
-  if (tid < V) slot[tid] = -1;
-  __syncthreads();
-  const int i0 = *s_i0;
-  if (tid < V) {
-    const int64_t i = (int64_t)i0 + tid;
-    if (i < n_intervals) {
-      const int64_t k = (int64_t)a.ranks_bev[a.interval_starts[i]] - ti.rank0;
-      if (k < ti.nvox) slot[k] = (int)i;
-    }
-  }
-  __syncthreads();
+// Occupancy mask of a tile: bit v set iff voxel v of the tile has an interval.
+// Column of an occupied voxel = number of occupied voxels below it = index of
+// its interval inside the tile (intervals are ascending in voxel rank).
+__device__ __forceinline__ unsigned long long wave_or(unsigned long long bit) {
+  for (int off = 32; off > 0; off >>= 1) bit |= __shfl_xor(bit, off);
+  return bit;
 }
 
 // ---------------------------------------------------------------------------
-// (2) Fused forward, channels-last (B,Z,Y,X,C): a tile of V voxels is one
-//     contiguous V*C-float region; lanes map to (voxel, VEC channels) in memory
-//     order, so every store instruction is 64 x VEC*4 contiguous bytes.
+// (2) Fused forward, channels-last (B,Z,Y,X,C): a tile is one contiguous
+//     64*C-float region; lanes map to (voxel, VEC channels) in memory order, so
+//     every store instruction is 64 x VEC*4 contiguous bytes.  No LDS data.
 // ---------------------------------------------------------------------------
-template <int VEC, int V>
+template <int VEC>
 __global__ __launch_bounds__(kBlock) void k_pool_fused_cl(
-    PoolArgs a, int c, int cq, int n_intervals, int64_t vpb,
-    int64_t tiles_per_batch, const int* __restrict__ tile_first,
-    float* __restrict__ out) {
-  __shared__ int slot[V];
-  __shared__ int s_i0;
+    PoolArgs a, const int4* __restrict__ plan, int c, int cq, int64_t vpb,
+    int64_t tiles_per_batch, float* __restrict__ out) {
   const int64_t t = blockIdx.x;
-  const TileInfo ti = tile_info(t, tiles_per_batch, vpb, V);
-  tile_slots<V>(a, n_intervals, tile_first, t, ti, slot, &s_i0);
+  const TileInfo ti = tile_info(t, tiles_per_batch, vpb);
+  const int4 pl = plan[t];
+  const int i0 = pl.x, cnt = pl.y;
   using VT = typename Vec<VEC>::T;
   float* obase = out + ti.rank0 * c;
   const int items = ti.nvox * cq;
+  if (cnt == 0) {
+    for (int item = threadIdx.x; item < items; item += kBlock)
+      reinterpret_cast<VT*>(obase)[item] = vzero<VEC>();
+    return;
+  }
+  const int lane = threadIdx.x & (kWave - 1);
+  unsigned long long bit = 0;
+  if (lane < cnt)
+    bit = 1ull << (int)((int64_t)a.ranks_bev[a.interval_starts[i0 + lane]] -
+                        ti.rank0);
+  const unsigned long long mask = wave_or(bit);
   for (int item = threadIdx.x; item < items; item += kBlock) {
     const int v = item / cq;
     const int ch = (item - v * cq) * VEC;
-    const int ii = slot[v];
     VT acc = vzero<VEC>();
-    if (ii >= 0)
+    if ((mask >> v) & 1ull) {
+      const int ii = i0 + __popcll(mask & ((1ull << v) - 1ull));
       acc = interval_sum<VEC>(a, c, a.interval_starts[ii],
                               a.interval_lengths[ii], ch);
-    *reinterpret_cast<VT*>(obase + (int64_t)v * c + ch) = acc;
+    }
+    reinterpret_cast<VT*>(obase)[item] = acc;
   }
 }
 
 // ---------------------------------------------------------------------------
 // (3) Fused forward, channels-first (B,C,Z,Y,X): the layout bev_pool_v2()
-//     returns.  Per tile of V = 64 voxels and slab of CS channels:
-//       gather phase : lanes = (interval of the tile, channel) -> feat rows are
-//                      read channel-contiguous; sums land in an LDS tile
-//                      [CS][V+1] (odd row stride: conflict-free both ways);
-//       store phase  : lanes = voxels; each wave stores 64 consecutive voxels
-//                      of one channel (256 contiguous bytes) per instruction;
-//                      empty voxels store 0 without touching LDS data.
+//     returns.  Per tile of 64 voxels and slab of `cs` channels, three load
+//     levels and then one wave-wide row store per channel:
+//       plan entry -> {interval starts, voxel of each interval, ranks_feat /
+//       ranks_depth of the tile's points (staged in LDS)} -> {feat rows, depth}
+//     gather: lanes = (interval, VEC channels): feat rows are read
+//       channel-contiguous, UNROLL loads in flight, serial fmaf chain;
+//     transpose: sums land in a compact LDS tile [cs][CAP+1], column = index of
+//       the interval inside the tile (odd row stride: conflict-free both ways);
+//     store: lanes = voxels; a wave stores 64 consecutive voxels of one
+//       channel (256 contiguous bytes) per instruction, non-temporal so the
+//       streamed volume does not evict the gathered rows from L2; empty voxels
+//       store 0.  Tiles with more than CAP intervals run as two 32-voxel halves.
 // ---------------------------------------------------------------------------
-constexpr int kVcf = 64;
+constexpr int kPmax = 1024;  // points staged per window (8 B each)
 
+template <int VEC, int CAP>
 __global__ __launch_bounds__(kBlock) void k_pool_fused_cf(
-    PoolArgs a, int c, int cs, int n_intervals, int64_t vpb,
-    int64_t tiles_per_batch, const int* __restrict__ tile_first,
-    float* __restrict__ out) {
-  extern __shared__ float lds[];  // [cs][kVcf+1] floats, then ints
-  constexpr int V = kVcf;
-  constexpr int LD = V + 1;
-  float* tile = lds;
-  int* slot = reinterpret_cast<int*>(lds + (size_t)cs * LD);  // [V]
-  int* vloc = slot + V;                                       // [V]
-  int* s_misc = vloc + V;                                     // [2]: i0, cnt
+    PoolArgs a, const int4* __restrict__ plan, int c, int cs, int64_t vpb,
+    int64_t tiles_per_batch, float* __restrict__ out) {
+  extern __shared__ float lds[];
+  constexpr int LDC = CAP + 1;
+  constexpr int UNROLL = 8;
+  constexpr int SB = 5;  // LDS reads batched ahead of the stores
+  constexpr int NW = kBlock / kWave;
+  float* tile = lds;                                             // [cs][LDC]
+  int* istart = reinterpret_cast<int*>(lds + (size_t)cs * LDC);  // [kTileV+2]
+  int* ivox = istart + kTileV + 2;                               // [kTileV]
+  int* s_rf = ivox + kTileV;                                     // [kPmax]
+  int* s_rd = s_rf + kPmax;                                      // [kPmax]
+
   const int tid = threadIdx.x;
+  const int lane = tid & (kWave - 1);
+  const int w = tid >> 6;
   const int64_t t = blockIdx.x;
   const int c0 = blockIdx.y * cs;
   const int nch = (c - c0) < cs ? (c - c0) : cs;
-  const TileInfo ti = tile_info(t, tiles_per_batch, vpb, V);
+  const TileInfo ti = tile_info(t, tiles_per_batch, vpb);
+  float* obase = out + ((int64_t)ti.b * c + c0) * vpb + ti.vox0;
 
-  // prologue: i0, slots, and the compact list vloc[j] = voxel of interval i0+j
-  if (tile_first != nullptr) {
-    if (tid == 0) s_misc[0] = tile_first[t];
-  } else if (tid < kWave) {
-    const int i0 = wave_lower_bound(a, n_intervals, ti.rank0);
-    if (tid == 0) s_misc[0] = i0;
-  }
-  if (tid < V) slot[tid] = -1;
-  __syncthreads();
-  const int i0 = s_misc[0];
-  if (tid < kWave) {
-    const int64_t i = (int64_t)i0 + tid;
-    bool in = false;
-    int k = 0;
-    if (i < n_intervals) {
-      const int64_t kk = (int64_t)a.ranks_bev[a.interval_starts[i]] - ti.rank0;
-      in = kk < ti.nvox;
-      k = (int)kk;
-    }
-    if (in) {
-      slot[k] = (int)i;
-      vloc[tid] = k;
-    }
-    const int cnt = __popcll(__ballot(in));
-    if (tid == 0) s_misc[1] = cnt;
-  }
-  __syncthreads();
-  const int cnt = s_misc[1];
+  const int4 pl = plan[t];
+  const int i0 = pl.x, cnt = pl.y, p0 = pl.z, npts = pl.w;
 
-  // gather phase
-  const int items = cnt * nch;
-  for (int item = tid; item < items; item += kBlock) {
-    const int j = item / nch;
-    const int cc = item - j * nch;
-    const int ii = i0 + j;
-    const float acc = interval_sum<1>(a, c, a.interval_starts[ii],
-                                      a.interval_lengths[ii], c0 + cc);
-    tile[cc * LD + vloc[j]] = acc;
+  if (cnt == 0) {  // empty tile: pure streaming zero fill
+    if (lane < ti.nvox)
+      for (int cc = w; cc < nch; cc += NW)
+        __builtin_nontemporal_store(0.f, obase + (int64_t)cc * vpb + lane);
+    return;
+  }
+  // level 2: everything that depends only on the plan entry
+  if (tid < cnt) {
+    const int st = a.interval_starts[i0 + tid];
+    istart[tid] = st - p0;
+    ivox[tid] = (int)((int64_t)a.ranks_bev[st] - ti.rank0);
+  }
+  if (tid == 0) istart[cnt] = npts;
+  {
+    const int n = npts < kPmax ? npts : kPmax;
+    for (int p = tid; p < n; p += kBlock) {
+      s_rf[p] = a.ranks_feat[p0 + p];
+      s_rd[p] = a.ranks_depth[p0 + p];
+    }
   }
   __syncthreads();
 
-  // store phase: wave w handles channels w, w+4, ...
-  const int v = tid & (V - 1);
-  const int w = tid >> 6;
-  const bool occupied = slot[v] >= 0;
-  if (v < ti.nvox) {
-    float* obase = out + ((int64_t)ti.b * c + c0) * vpb + ti.vox0 + v;
-    for (int cc = w; cc < nch; cc += kBlock / kWave) {
-      const float val = occupied ? tile[cc * LD + v] : 0.f;
-      obase[(int64_t)cc * vpb] = val;
+  const unsigned long long mask =
+      wave_or(lane < cnt ? (1ull << ivox[lane]) : 0ull);
+  using VT = typename Vec<VEC>::T;
+  const int nq = nch / VEC;
+  const int npass = cnt > CAP ? 2 : 1;
+  const int jsplit = __popcll(mask & 0xffffffffull);  // intervals in voxels 0..31
+  int base = 0;  // first staged point (relative to p0)
+  for (int pass = 0; pass < npass; ++pass) {
+    const int ja = (npass == 2 && pass == 1) ? jsplit : 0;
+    const int jb = (npass == 2 && pass == 0) ? jsplit : cnt;
+    int j0 = ja;
+    while (j0 < jb) {
+      // group [j0, j1): consecutive intervals whose points are staged
+      int j1 = j0;
+      while (j1 < jb && istart[j1 + 1] - base <= kPmax) ++j1;
+      if (j1 == j0) {
+        const int st = istart[j0];
+        const int len = istart[j0 + 1] - st;
+        if (len > kPmax) {
+          // one interval longer than the window: straight from global memory
+          for (int q = tid; q < nq; q += kBlock) {
+            const VT acc =
+                interval_sum<VEC>(a, c, p0 + st, len, c0 + q * VEC);
+            const float* ap = reinterpret_cast<const float*>(&acc);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k)
+              tile[(q * VEC + k) * LDC + (j0 - ja)] = ap[k];
+          }
+          ++j0;
+          continue;
+        }
+        // restage the window from interval j0
+        __syncthreads();
+        base = st;
+        const int n = (npts - base) < kPmax ? (npts - base) : kPmax;
+        for (int p = tid; p < n; p += kBlock) {
+          s_rf[p] = a.ranks_feat[p0 + base + p];
+          s_rd[p] = a.ranks_depth[p0 + base + p];
+        }
+        __syncthreads();
+        continue;
+      }
+      const int items = (j1 - j0) * nq;
+      for (int item = tid; item < items; item += kBlock) {
+        const int j = j0 + item / nq;
+        const int q = item - (j - j0) * nq;
+        const int st = istart[j] - base;
+        const int len = istart[j + 1] - istart[j];
+        const float* fcol = a.feat + c0 + q * VEC;
+        VT acc = vzero<VEC>();
+        int i = 0;
+        for (; i + UNROLL <= len; i += UNROLL) {
+          VT f[UNROLL];
+          float d[UNROLL];
+#pragma unroll
+          for (int u = 0; u < UNROLL; ++u) {
+            f[u] = *reinterpret_cast<const VT*>(
+                fcol + (int64_t)s_rf[st + i + u] * c);
+            d[u] = a.depth[s_rd[st + i + u]];
+          }
+#pragma unroll
+          for (int u = 0; u < UNROLL; ++u) vfma<VEC>(acc, f[u], d[u]);
+        }
+        for (; i < len; ++i) {
+          const VT f =
+              *reinterpret_cast<const VT*>(fcol + (int64_t)s_rf[st + i] * c);
+          vfma<VEC>(acc, f, a.depth[s_rd[st + i]]);
+        }
+        const float* ap = reinterpret_cast<const float*>(&acc);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k)
+          tile[(q * VEC + k) * LDC + (j - ja)] = ap[k];
+      }
+      j0 = j1;
+    }
+    __syncthreads();
+    if (npass == 1) {
+      const bool occupied = (mask >> lane) & 1ull;
+      const int col = __popcll(mask & ((1ull << lane) - 1ull));
+      if (lane < ti.nvox) {
+        float* op = obase + lane;
+        int cc = w;
+        for (; cc + (SB - 1) * NW < nch; cc += SB * NW) {
+          float vals[SB];
+#pragma unroll
+          for (int u = 0; u < SB; ++u)
+            vals[u] = occupied ? tile[(cc + NW * u) * LDC + col] : 0.f;
+#pragma unroll
+          for (int u = 0; u < SB; ++u)
+            __builtin_nontemporal_store(vals[u],
+                                        op + (int64_t)(cc + NW * u) * vpb);
+        }
+        for (; cc < nch; cc += NW)
+          __builtin_nontemporal_store(occupied ? tile[cc * LDC + col] : 0.f,
+                                      op + (int64_t)cc * vpb);
+      }
+    } else {
+      // half tile (32 voxels): one wave instruction = 2 channels x 128 B
+      const int v = pass * 32 + (lane & 31);
+      const bool occupied = (mask >> v) & 1ull;
+      const int col = __popcll(mask & ((1ull << v) - 1ull)) - ja;
+      if (v < ti.nvox)
+        for (int cc = 2 * w + (lane >> 5); cc < nch; cc += 2 * NW)
+          __builtin_nontemporal_store(occupied ? tile[cc * LDC + col] : 0.f,
+                                      obase + (int64_t)cc * vpb + v);
+      if (pass == 0) __syncthreads();  // the tile is reused by the second half
     }
   }
-}
-
-// ---------------------------------------------------------------------------
-// (4) Tile table: tile_first[t] = lower_bound(key, first rank of tile t).
-//     One wave per tile boundary (64-ary search).
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_tile_table(
-    PoolArgs a, int n_intervals, int64_t vpb, int64_t tiles_per_batch, int V,
-    int64_t n_tiles, int* __restrict__ tile_first) {
-  const int64_t t = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
-  if (t > n_tiles) return;  // wave-uniform
-  int r;
-  if (t == n_tiles) {
-    r = n_intervals;
-  } else {
-    const TileInfo ti = tile_info(t, tiles_per_batch, vpb, V);
-    r = wave_lower_bound(a, n_intervals, ti.rank0);
-  }
-  if ((threadIdx.x & (kWave - 1)) == 0) tile_first[t] = r;
 }
 
 // ---------------------------------------------------------------------------
@@ -476,11 +554,38 @@ int veon_bev_pool_v2_bwd(int c, int n_intervals, const float* out_grad,
   return launch_status();
 }
 
-static int cf_slab(int c) { return c <= 128 ? c : 64; }
+int veon_bev_pool_tile_voxels(void) { return kTileV; }
 
-int veon_bev_pool_tile_voxels(int c, int out_layout) {
-  (void)c;
-  return out_layout == VEON_LAYOUT_BCZYX ? kVcf : 64;
+int64_t veon_bev_pool_plan_ints(int batch, int64_t voxels_per_batch) {
+  if (batch <= 0 || voxels_per_batch <= 0) return 0;
+  const int64_t n_tiles =
+      ((voxels_per_batch + kTileV - 1) / kTileV) * (int64_t)batch;
+  return 4 * n_tiles + 2 * (n_tiles + 1);  // plan entries + build scratch
+}
+
+int veon_bev_pool_plan(int n_intervals, int n_points, int batch,
+                       int64_t voxels_per_batch, const int* ranks_bev,
+                       const int* interval_starts, int* plan, void* stream) {
+  if (n_intervals < 0 || n_points < 0 || batch <= 0 || voxels_per_batch <= 0 ||
+      !plan)
+    return VEON_ERR_BAD_ARG;
+  if (n_intervals > 0 && (!ranks_bev || !interval_starts))
+    return VEON_ERR_BAD_ARG;
+  if ((reinterpret_cast<uintptr_t>(plan) & 15u) != 0) return VEON_ERR_BAD_ARG;
+  const int64_t tiles_per_batch = (voxels_per_batch + kTileV - 1) / kTileV;
+  const int64_t n_tiles = tiles_per_batch * batch;
+  if (n_tiles > 0x3fffffffLL) return VEON_ERR_BAD_ARG;
+  int* tile_first = plan + 4 * n_tiles;
+  int* tile_point = tile_first + (n_tiles + 1);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const unsigned b1 = (unsigned)(((int64_t)n_intervals + 1 + kBlock - 1) / kBlock);
+  hipLaunchKernelGGL(k_plan_bounds, dim3(b1), dim3(kBlock), 0, s, ranks_bev,
+                     interval_starts, n_intervals, n_points, voxels_per_batch,
+                     tiles_per_batch, n_tiles, tile_first, tile_point);
+  const unsigned b2 = (unsigned)((n_tiles + kBlock - 1) / kBlock);
+  hipLaunchKernelGGL(k_plan_pack, dim3(b2), dim3(kBlock), 0, s, tile_first,
+                     tile_point, n_tiles, reinterpret_cast<int4*>(plan));
+  return launch_status();
 }
 
 int veon_bev_pool_v2_fwd_fused(int c, int n_intervals, int batch,
@@ -488,10 +593,10 @@ int veon_bev_pool_v2_fwd_fused(int c, int n_intervals, int batch,
                                const float* feat, const int* ranks_depth,
                                const int* ranks_feat, const int* ranks_bev,
                                const int* interval_starts,
-                               const int* interval_lengths,
-                               const int* tile_first, float* out,
-                               int out_layout, void* stream) {
-  if (c <= 0 || n_intervals < 0 || batch <= 0 || voxels_per_batch <= 0 || !out)
+                               const int* interval_lengths, const int* plan,
+                               float* out, int out_layout, void* stream) {
+  if (c <= 0 || n_intervals < 0 || batch <= 0 || voxels_per_batch <= 0 ||
+      !out || !plan)
     return VEON_ERR_BAD_ARG;
   if (out_layout != VEON_LAYOUT_BZYXC && out_layout != VEON_LAYOUT_BCZYX)
     return VEON_ERR_BAD_ARG;
@@ -501,56 +606,43 @@ int veon_bev_pool_v2_fwd_fused(int c, int n_intervals, int batch,
     return VEON_ERR_BAD_ARG;
   if ((int64_t)batch * voxels_per_batch > 0x7fffffffLL)
     return VEON_ERR_BAD_ARG;  // ranks_bev is int32 (the reference ABI)
+  if ((reinterpret_cast<uintptr_t>(plan) & 15u) != 0) return VEON_ERR_BAD_ARG;
   PoolArgs a{depth, feat, ranks_depth, ranks_feat, ranks_bev, interval_starts,
              interval_lengths};
   hipStream_t s = static_cast<hipStream_t>(stream);
-  constexpr int V = 64;
-  const int64_t tiles_per_batch = (voxels_per_batch + V - 1) / V;
+  const int64_t tiles_per_batch = (voxels_per_batch + kTileV - 1) / kTileV;
   const int64_t n_tiles = tiles_per_batch * batch;
-  if (n_tiles > 0x7fffffffLL) return VEON_ERR_BAD_ARG;
+  if (n_tiles > 0x3fffffffLL) return VEON_ERR_BAD_ARG;
+  const int4* plan4 = reinterpret_cast<const int4*>(plan);
+  const bool v4 = (c % 4 == 0) && aligned16(feat);
   if (out_layout == VEON_LAYOUT_BZYXC) {
-    const bool v4 = (c % 4 == 0) && aligned16(feat) && aligned16(out);
-    if (v4)
-      hipLaunchKernelGGL((k_pool_fused_cl<4, V>), dim3((unsigned)n_tiles),
-                         dim3(kBlock), 0, s, a, c, c / 4, n_intervals,
-                         voxels_per_batch, tiles_per_batch, tile_first, out);
+    if (v4 && aligned16(out))
+      hipLaunchKernelGGL(k_pool_fused_cl<4>, dim3((unsigned)n_tiles),
+                         dim3(kBlock), 0, s, a, plan4, c, c / 4,
+                         voxels_per_batch, tiles_per_batch, out);
     else
-      hipLaunchKernelGGL((k_pool_fused_cl<1, V>), dim3((unsigned)n_tiles),
-                         dim3(kBlock), 0, s, a, c, c, n_intervals,
-                         voxels_per_batch, tiles_per_batch, tile_first, out);
-  } else {
-    const int cs = cf_slab(c);
-    const int slabs = (c + cs - 1) / cs;
-    const size_t lds = (size_t)cs * (kVcf + 1) * sizeof(float) +
-                       (2 * kVcf + 2) * sizeof(int);
-    hipLaunchKernelGGL(k_pool_fused_cf, dim3((unsigned)n_tiles, (unsigned)slabs),
-                       dim3(kBlock), lds, s, a, c, cs, n_intervals,
-                       voxels_per_batch, tiles_per_batch, tile_first, out);
+      hipLaunchKernelGGL(k_pool_fused_cl<1>, dim3((unsigned)n_tiles),
+                         dim3(kBlock), 0, s, a, plan4, c, c, voxels_per_batch,
+                         tiles_per_batch, out);
+    return launch_status();
   }
-  return launch_status();
-}
-
-int veon_bev_pool_tile_table(int n_intervals, int batch,
-                             int64_t voxels_per_batch, int tile_voxels,
-                             const int* ranks_bev, const int* interval_starts,
-                             int* tile_first, void* stream) {
-  if (n_intervals < 0 || batch <= 0 || voxels_per_batch <= 0 ||
-      tile_voxels <= 0 || !tile_first)
-    return VEON_ERR_BAD_ARG;
-  if (n_intervals > 0 && (!ranks_bev || !interval_starts))
-    return VEON_ERR_BAD_ARG;
-  PoolArgs a{nullptr, nullptr, nullptr, nullptr, ranks_bev, interval_starts,
-             nullptr};
-  const int64_t tiles_per_batch =
-      (voxels_per_batch + tile_voxels - 1) / tile_voxels;
-  const int64_t n_tiles = tiles_per_batch * batch;
-  const int waves_per_block = kBlock / kWave;
-  const int64_t blocks = (n_tiles + 1 + waves_per_block - 1) / waves_per_block;
-  if (blocks > 0x7fffffffLL) return VEON_ERR_BAD_ARG;
-  hipLaunchKernelGGL(k_tile_table, dim3((unsigned)blocks), dim3(kBlock), 0,
-                     static_cast<hipStream_t>(stream), a, n_intervals,
-                     voxels_per_batch, tiles_per_batch, tile_voxels, n_tiles,
-                     tile_first);
+  // channels-first: channel slab and LDS tile width by problem shape
+  const int cs = c <= 128 ? c : 64;
+  const int slabs = (c + cs - 1) / cs;
+  const bool dense = (int64_t)n_intervals > 12 * n_tiles;  // mean intervals/tile
+  const int cap = dense ? 64 : 32;
+  const size_t lds = (size_t)cs * (cap + 1) * sizeof(float) +
+                     (size_t)(2 * kTileV + 2 + 2 * kPmax) * sizeof(int);
+  const dim3 grid((unsigned)n_tiles, (unsigned)slabs);
+#define VEON_LAUNCH_CF(VEC, CAP)                                              \
+  hipLaunchKernelGGL((k_pool_fused_cf<VEC, CAP>), grid, dim3(kBlock), lds, s, \
+                     a, plan4, c, cs, voxels_per_batch, tiles_per_batch, out)
+  if (v4) {
+    if (dense) VEON_LAUNCH_CF(4, 64); else VEON_LAUNCH_CF(4, 32);
+  } else {
+    if (dense) VEON_LAUNCH_CF(1, 64); else VEON_LAUNCH_CF(1, 32);
+  }
+#undef VEON_LAUNCH_CF
   return launch_status();
 }
 

@@ -109,8 +109,7 @@ class LSSCore(_Base):
         B = coor.shape[0]
         vpb = int(self.grid_size[2]) * int(self.grid_size[1]) * \
             int(self.grid_size[0])
-        _bp.build_tile_table(self.ranks_bev, self.interval_starts, B, vpb,
-                             self.out_channels)
+        _bp.build_plan(self.ranks_bev, self.interval_starts, B, vpb)
 
     def _bev_feat_shape(self, B, C):
         return (B, int(self.grid_size[2]), int(self.grid_size[1]),

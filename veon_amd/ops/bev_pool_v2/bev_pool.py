@@ -56,7 +56,7 @@ def _prep_inputs(depth, feat, ranks_depth, ranks_feat, ranks_bev,
                  interval_starts, interval_lengths):
     # casts of bev_pool.py:19-25 (no-ops for what the prepare produces)
     tag = getattr(interval_starts, '_veon_sorted', None)
-    tiles = getattr(interval_starts, '_veon_tile_first', None)
+    plan = getattr(interval_starts, '_veon_plan', None)
     depth = depth.contiguous().float()
     feat = feat.contiguous().float()
     ranks_bev = ranks_bev.contiguous().int()
@@ -66,29 +66,31 @@ def _prep_inputs(depth, feat, ranks_depth, ranks_feat, ranks_bev,
     interval_starts = interval_starts.contiguous().int()
     if tag is not None:
         interval_starts._veon_sorted = tag
-    if tiles is not None:
-        interval_starts._veon_tile_first = tiles
+    if plan is not None:
+        interval_starts._veon_plan = plan
     return (depth, feat, ranks_depth, ranks_feat, ranks_bev, interval_starts,
             interval_lengths)
 
 
-def build_tile_table(ranks_bev, interval_starts, batch, voxels_per_batch,
-                     channels=0, layout=_lib.LAYOUT_BCZYX):
-    """Optional per-tile first-interval table for the fused kernels; cache it
-    with the ranks (accelerate=True).  Attached to ``interval_starts``."""
+def build_plan(ranks_bev, interval_starts, batch, voxels_per_batch,
+               attach=True):
+    """Per-tile plan of the fused kernels (include/veon_hip.h
+    ``veon_bev_pool_plan``).  With ``attach`` it is cached on
+    ``interval_starts`` -- do that when the ranks themselves are cached
+    (accelerate=True); otherwise it is rebuilt per call (two tiny kernels)."""
     dev = _lib.require_device(ranks_bev, interval_starts)
     L = _lib.lib()
-    v = L.veon_bev_pool_tile_voxels(channels, layout)
-    n_tiles = batch * ((voxels_per_batch + v - 1) // v)
-    table = torch.empty(n_tiles + 1, dtype=torch.int32, device=dev)
+    n_ints = L.veon_bev_pool_plan_ints(batch, voxels_per_batch)
+    plan = torch.empty(n_ints, dtype=torch.int32, device=dev)
     with torch.cuda.device(dev):
-        st = L.veon_bev_pool_tile_table(
-            interval_starts.numel(), batch, voxels_per_batch, v,
-            _lib.ptr(ranks_bev), _lib.ptr(interval_starts), _lib.ptr(table),
-            _lib.stream_ptr(dev))
-    _lib.check(st, 'veon_bev_pool_tile_table')
-    interval_starts._veon_tile_first = table
-    return table
+        st = L.veon_bev_pool_plan(
+            interval_starts.numel(), ranks_bev.numel(), batch,
+            voxels_per_batch, _lib.ptr(ranks_bev), _lib.ptr(interval_starts),
+            _lib.ptr(plan), _lib.stream_ptr(dev))
+    _lib.check(st, 'veon_bev_pool_plan')
+    if attach:
+        interval_starts._veon_plan = (plan, batch, voxels_per_batch)
+    return plan
 
 
 def _fused_forward(depth, feat, ranks_depth, ranks_feat, ranks_bev,
@@ -100,13 +102,18 @@ def _fused_forward(depth, feat, ranks_depth, ranks_feat, ranks_bev,
         out = torch.empty((B, C, Z, Y, X), dtype=torch.float32, device=dev)
     else:
         out = torch.empty((B, Z, Y, X, C), dtype=torch.float32, device=dev)
-    tiles = getattr(interval_starts, '_veon_tile_first', None)
+    cached = getattr(interval_starts, '_veon_plan', None)
+    if cached is not None and cached[1] == B and cached[2] == Z * Y * X:
+        plan = cached[0]
+    else:
+        plan = build_plan(ranks_bev, interval_starts, B, Z * Y * X,
+                          attach=False)
     with torch.cuda.device(dev):
         st = _lib.lib().veon_bev_pool_v2_fwd_fused(
             C, interval_starts.numel(), B, Z * Y * X, _lib.ptr(depth),
             _lib.ptr(feat), _lib.ptr(ranks_depth), _lib.ptr(ranks_feat),
             _lib.ptr(ranks_bev), _lib.ptr(interval_starts),
-            _lib.ptr(interval_lengths), _lib.ptr(tiles), _lib.ptr(out), layout,
+            _lib.ptr(interval_lengths), _lib.ptr(plan), _lib.ptr(out), layout,
             _lib.stream_ptr(dev))
     _lib.check(st, 'veon_bev_pool_v2_fwd_fused')
     return out
