@@ -104,6 +104,62 @@ int veon_bev_pool_v2_fwd_fused(int c, int n_intervals, int batch,
                                const int *interval_lengths, const int *plan,
                                float *out, int out_layout, void *stream);
 
+/*
+ * The per-camera 3x3 algebra of get_lidar_coor
+ * (view_transformer_raw.py:145,151): post_rots_inv = inv(post_rots),
+ * combine = sensor2ego[:3,:3] @ inv(cam2imgs), trans = sensor2ego[:3,3], for BN
+ * cameras (sensor2ego (BN,4,4), the others (BN,3,3)).  Stream-capturable
+ * replacement for the reference's two torch.inverse calls: adjugate inverse in
+ * double precision rounded to float (agrees with LAPACK / rocSOLVER to their
+ * own rounding error).
+ */
+int veon_camera_matrices(int BN, const float *sensor2ego, const float *cam2imgs,
+                         const float *post_rots, float *post_rots_inv,
+                         float *combine, float *trans, void *stream);
+
+/*
+ * Frustum -> ego coordinates: the per-point half of get_lidar_coor
+ * (mmdet3d/models/necks/view_transformer_raw.py:144-155).  xs[W], ys[H], ds[D]
+ * are the frustum axes (create_frustum, :91-119); post_rots_inv = inv(post_rots)
+ * and combine = sensor2ego[:3,:3] @ inv(cam2imgs) are (B,N,3,3), post_trans /
+ * trans (B,N,3), bda (B,3,3).  coor is (B,N,D,H,W,3).  Bit-identical to the
+ * reference's CPU result for identical matrices.
+ */
+int veon_lidar_coor(int B, int N, int D, int H, int W, const float *xs,
+                    const float *ys, const float *ds,
+                    const float *post_rots_inv, const float *post_trans,
+                    const float *combine, const float *trans, const float *bda,
+                    float *coor, void *stream);
+
+/*
+ * voxel_pooling_prepare_v2 (view_transformer_raw.py:244-302) as a counting
+ * sort on the device, no host synchronisation inside.
+ *   coor != NULL : voxelise the given (B,N,D,H,W,3) coordinates (the method's
+ *                  own contract);
+ *   coor == NULL : fuse the geometry of veon_lidar_coor in, never
+ *                  materialising the coordinates.
+ * grid_lower / grid_interval / grid_size are HOST float[3] (the reference's
+ * float32 grid tensors, :74-89).  Outputs must hold B*N*D*H*W int32 each; the
+ * first counts[0] (points kept) / counts[1] (intervals) entries are valid,
+ * counts is DEVICE int[2].  Order inside an interval is ascending ranks_depth
+ * (the reference's unstable argsort leaves it unspecified).  `plan` (optional,
+ * veon_bev_pool_plan_ints(B, voxels_per_batch) int32, 16-B aligned; needs
+ * voxels_per_batch % 64 == 0) receives the fused pool kernels' plan for free.
+ * workspace: veon_lss_prepare_workspace_bytes(B*N*D*H*W, B*voxels_per_batch).
+ */
+int64_t veon_lss_prepare_workspace_bytes(int64_t num_points,
+                                         int64_t num_voxels_total);
+int veon_lss_prepare(int B, int N, int D, int H, int W, const float *coor,
+                     const float *xs, const float *ys, const float *ds,
+                     const float *post_rots_inv, const float *post_trans,
+                     const float *combine, const float *trans, const float *bda,
+                     const float *grid_lower, const float *grid_interval,
+                     const float *grid_size, int64_t voxels_per_batch,
+                     void *workspace, int64_t workspace_bytes, int *ranks_bev,
+                     int *ranks_depth, int *ranks_feat, int *interval_starts,
+                     int *interval_lengths, int *plan, int *counts,
+                     void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -174,3 +174,115 @@ def test_full_veon_shape_prepare_hashes(full_cases):
     assert helpers.sha(rf.cpu().numpy()) == e['sha_ranks_feat']
     assert helpers.sha(st.cpu().numpy()) == e['sha_interval_starts']
     assert helpers.sha(ln.cpu().numpy()) == e['sha_interval_lengths']
+
+
+# ---------------------------------------------------------------- HIP prepare
+def _cpu_matrices(g):
+    from veon_amd import lss_prepare
+    return lss_prepare.camera_matrices(
+        torch.from_numpy(g['sensor2ego']), torch.from_numpy(g['intrins']),
+        torch.from_numpy(g['post_rots']))
+
+
+@pytest.mark.parametrize('name', ['lss_small', 'lss_small_b2', 'lss_mid'])
+def test_hip_prepare_fused_geometry_exact(name):
+    """Geometry fused into the counting-sort prepare (coordinates never
+    materialised): ranks / intervals exactly the reference's."""
+    from veon_amd import lss_prepare
+    g = load_golden(name)
+    vt = _raw_from_golden(g)
+    pri, comb, trans = _cpu_matrices(g)
+    out = lss_prepare.prepare_from_matrices(
+        vt.frustum, pri.to(DEV), dev(g['post_trans']), comb.to(DEV),
+        trans.to(DEV), dev(g['bda']), vt.grid_lower_bound, vt.grid_interval,
+        vt.grid_size)
+    for got, key in zip(out, ('ranks_bev', 'ranks_depth', 'ranks_feat',
+                              'interval_starts', 'interval_lengths')):
+        assert got.dtype == torch.int32
+        assert np.array_equal(got.cpu().numpy(), g[key]), key
+
+
+@pytest.mark.parametrize('name', ['lss_small', 'lss_small_b2'])
+def test_prepare_plan_equals_standalone_plan(name):
+    """The plan the prepare's scan emits == veon_bev_pool_plan on its output."""
+    from veon_amd.ops.bev_pool_v2 import bev_pool as bp
+    g = load_golden(name)
+    vt = _raw_from_golden(g)
+    rb, rd, rf, st, ln = vt.voxel_pooling_prepare_v2(dev(g['coor']))
+    plan, B, vpb = st._veon_plan
+    n_tiles = B * (vpb // 64)
+    ref = bp.build_plan(rb, st, B, vpb, attach=False)
+    assert torch.equal(plan[:4 * n_tiles], ref[:4 * n_tiles])
+
+
+@pytest.mark.parametrize('name', ['lss_small_b2', 'lss_mid'])
+def test_sync_free_lift_equals_regular(name):
+    g = load_golden(name)
+    inp = _inputs(g)
+    vt = _raw_from_golden(g)
+    with torch.no_grad():
+        a = vt([dev(g['feat'])] + inp, dev(g['two_hot']))
+        vt.sync_free = True
+        if vt._bev_feat_shape(1, 1)[1] * vt._bev_feat_shape(1, 1)[2] * \
+                vt._bev_feat_shape(1, 1)[3] % 64:
+            with pytest.raises(Exception):
+                vt([dev(g['feat'])] + inp, dev(g['two_hot']))
+            return
+        b = vt([dev(g['feat'])] + inp, dev(g['two_hot']))
+    # same kernels, camera matrices by the capturable adjugate kernel instead
+    # of rocSOLVER: equal up to a point hopping a voxel boundary
+    diff = (a != b).float().mean().item()
+    assert diff < 1e-3, diff
+    np.testing.assert_allclose(a.sum().item(), b.sum().item(), rtol=1e-4)
+
+
+def test_camera_matrices_kernel_matches_torch_inverse():
+    from veon_amd import lss_prepare, lss_prepare_hip
+    g = load_golden('lss_small_b2')
+    want = _cpu_matrices(g)
+    got = lss_prepare_hip.camera_matrices(dev(g['sensor2ego']), dev(g['intrins']),
+                                          dev(g['post_rots']))
+    for a, b in zip(got, want):
+        np.testing.assert_allclose(a.cpu().numpy(), b.numpy(), rtol=2e-6, atol=1e-9)
+
+
+def test_sync_free_lift_is_graph_capturable():
+    g = load_golden('lss_small_b2')
+    inp = _inputs(g)
+    vt = _raw_from_golden(g)
+    vt.sync_free = True
+    feat, depth = dev(g['feat']), dev(g['two_hot'])
+    with torch.no_grad():
+        want = vt([feat] + inp, depth)
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            vt([feat] + inp, depth)
+        torch.cuda.current_stream().wait_stream(s)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = vt([feat] + inp, depth)
+        out.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+    assert torch.equal(out, want)
+
+
+def test_full_s2_prepare_hashes_fused(full_cases):
+    e = full_cases['S2']
+    from veon_amd import lss_prepare
+    vt = build_neck(dict(type='LSSViewTransformer', grid_config=e['grid_config'],
+                         input_size=tuple(e['input_size']), in_channels=8,
+                         out_channels=e['C'], collapse_z=False)).to(DEV)
+    rig = synthetic.make_rig(1, e['n_cams'], tuple(e['input_size']))
+    g = {k: v.numpy() for k, v in rig.items()}
+    pri, comb, trans = _cpu_matrices(g)
+    rb, rd, rf, st, ln = lss_prepare.prepare_from_matrices(
+        vt.frustum, pri.to(DEV), dev(g['post_trans']), comb.to(DEV),
+        trans.to(DEV), dev(g['bda']), vt.grid_lower_bound, vt.grid_interval,
+        vt.grid_size)
+    assert rb.numel() == e['P_kept'] and st.numel() == e['n_intervals']
+    for t, k in ((rb, 'sha_ranks_bev'), (rd, 'sha_ranks_depth'),
+                 (rf, 'sha_ranks_feat'), (st, 'sha_interval_starts'),
+                 (ln, 'sha_interval_lengths')):
+        assert helpers.sha(t.cpu().numpy()) == e[k], k

@@ -29,6 +29,11 @@ _SIGNATURES = {
     'veon_bev_pool_tile_voxels': (_ci, []),
     'veon_bev_pool_plan_ints': (_i64, [_ci, _i64]),
     'veon_bev_pool_plan': (_ci, [_ci, _ci, _ci, _i64, _vp, _vp, _vp, _vp]),
+    'veon_camera_matrices': (_ci, [_ci] + [_vp] * 6 + [_vp]),
+    'veon_lidar_coor': (_ci, [_ci] * 5 + [_vp] * 9 + [_vp]),
+    'veon_lss_prepare_workspace_bytes': (_i64, [_i64, _i64]),
+    'veon_lss_prepare': (_ci, [_ci] * 5 + [_vp] * 9 + [_vp] * 3 + [_i64, _vp, _i64]
+                         + [_vp] * 7 + [_vp]),
 }
 
 LAYOUT_BZYXC = 0

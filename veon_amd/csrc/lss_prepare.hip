@@ -1,0 +1,497 @@
+// Index half of the lift on MI355X: frustum geometry, voxelisation, sort by
+// voxel rank, run-length intervals and the pool plan -- hand-written HIP.
+//
+// Replaces the torch-op sequence of get_lidar_coor + voxel_pooling_prepare_v2
+// (mmdet3d/models/necks/view_transformer_raw.py:121-158, 244-302), which is
+// sort-bound and host-syncing.  Keys are dense small integers (voxel ranks), so
+// the sort is a counting sort: the voxel histogram IS the run-length encoding.
+//
+//   k_voxel_keys   one lane per frustum point: coordinates (optional output),
+//                  voxel, in-grid test, float32 rank -> key; histogram by atomics
+//   k_scan_*       exclusive scan of the histogram over all voxels (3 kernels),
+//                  emits interval_starts / interval_lengths, counts and the
+//                  64-voxel tile plan of the fused pool kernels
+//   k_scatter      points -> their voxel's slot range (atomic cursor)
+//   k_rank_in_bin  deterministic stable order inside every interval
+//                  (ascending point index) by rank-counting
+//
+// Arithmetic follows the C oracle operation for operation (compiled with
+// -ffp-contract=off): ((0 + m0*x) + m1*y) + m2*z for the 3x3 products,
+// (coor - lower) / interval, truncation toward zero, float32 rank.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/veon_hip.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kTileV = 64;        // must match bev_pool_v2.hip
+constexpr int kScanItems = 4;     // bins per thread in the scan kernels
+constexpr int kScanBlock = kBlock * kScanItems;  // 1024 bins = 16 tiles
+
+struct Geometry {
+  const float* xs;             // [W] frustum pixel x
+  const float* ys;             // [H] frustum pixel y
+  const float* ds;             // [D] frustum depth
+  const float* post_rots_inv;  // [B,N,3,3]
+  const float* post_trans;     // [B,N,3]
+  const float* combine;        // [B,N,3,3]
+  const float* trans;          // [B,N,3]
+  const float* bda;            // [B,3,3]
+};
+
+struct GridF {
+  float lo[3];
+  float step[3];
+  float size[3];
+};
+
+__device__ __forceinline__ void mat3_vec(const float* __restrict__ m, float x,
+                                         float y, float z, float* o) {
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    float acc = 0.f;
+    acc = acc + m[r * 3 + 0] * x;
+    acc = acc + m[r * 3 + 1] * y;
+    acc = acc + m[r * 3 + 2] * z;
+    o[r] = acc;
+  }
+}
+
+// view_transformer_raw.py:144-155
+__device__ __forceinline__ void point_coor(const Geometry& g, int bn, int b,
+                                           int d, int h, int w, float* o) {
+  const float* pt = g.post_trans + bn * 3;
+  const float fx = g.xs[w] - pt[0];
+  const float fy = g.ys[h] - pt[1];
+  const float fz = g.ds[d] - pt[2];
+  float p[3], q[3];
+  mat3_vec(g.post_rots_inv + bn * 9, fx, fy, fz, p);
+  const float cx = p[0] * p[2], cy = p[1] * p[2], cz = p[2];
+  mat3_vec(g.combine + bn * 9, cx, cy, cz, q);
+  const float* tr = g.trans + bn * 3;
+  q[0] += tr[0];
+  q[1] += tr[1];
+  q[2] += tr[2];
+  mat3_vec(g.bda + b * 9, q[0], q[1], q[2], o);
+}
+
+// The (B,N) camera algebra of get_lidar_coor (:145, :151) without
+// torch.inverse (rocSOLVER is not stream-capturable): inverses by the adjugate
+// in double precision, rounded to float; the 3x3 product in float with the
+// k-ascending accumulation torch's small bmm uses.
+__device__ __forceinline__ void inv3_f64(const float* m, float* o) {
+  const double a = m[0], b = m[1], c = m[2], d = m[3], e = m[4], f = m[5],
+               g = m[6], h = m[7], i = m[8];
+  const double A = e * i - f * h, B = -(d * i - f * g), C = d * h - e * g;
+  const double det = a * A + b * B + c * C;
+  const double r = 1.0 / det;
+  o[0] = (float)(A * r);
+  o[1] = (float)(-(b * i - c * h) * r);
+  o[2] = (float)((b * f - c * e) * r);
+  o[3] = (float)(B * r);
+  o[4] = (float)((a * i - c * g) * r);
+  o[5] = (float)(-(a * f - c * d) * r);
+  o[6] = (float)(C * r);
+  o[7] = (float)(-(a * h - b * g) * r);
+  o[8] = (float)((a * e - b * d) * r);
+}
+
+__global__ __launch_bounds__(kBlock) void k_camera_matrices(
+    int BN, const float* __restrict__ sensor2ego, const float* __restrict__ cam2imgs,
+    const float* __restrict__ post_rots, float* __restrict__ post_rots_inv,
+    float* __restrict__ combine, float* __restrict__ trans) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= BN) return;
+  float pri[9], kin[9];
+  inv3_f64(post_rots + i * 9, pri);
+  inv3_f64(cam2imgs + i * 9, kin);
+  const float* s = sensor2ego + i * 16;
+  for (int r = 0; r < 3; ++r) {
+    for (int cidx = 0; cidx < 3; ++cidx) {
+      float acc = 0.f;
+      acc = acc + s[r * 4 + 0] * kin[0 * 3 + cidx];
+      acc = acc + s[r * 4 + 1] * kin[1 * 3 + cidx];
+      acc = acc + s[r * 4 + 2] * kin[2 * 3 + cidx];
+      combine[i * 9 + r * 3 + cidx] = acc;
+    }
+    trans[i * 3 + r] = s[r * 4 + 3];
+  }
+  for (int k = 0; k < 9; ++k) post_rots_inv[i * 9 + k] = pri[k];
+}
+
+__global__ __launch_bounds__(kBlock) void k_lidar_coor(
+    Geometry g, int N, int D, int H, int W, int64_t P,
+    float* __restrict__ coor) {
+  const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (p >= P) return;
+  const int w = (int)(p % W);
+  const int h = (int)((p / W) % H);
+  const int d = (int)((p / ((int64_t)W * H)) % D);
+  const int bn = (int)(p / ((int64_t)W * H * D));
+  float o[3];
+  point_coor(g, bn, bn / N, d, h, w, o);
+  coor[p * 3 + 0] = o[0];
+  coor[p * 3 + 1] = o[1];
+  coor[p * 3 + 2] = o[2];
+}
+
+// view_transformer_raw.py:267-286: voxel, filter, float32 rank.  key = -1 when
+// the point is dropped.
+__device__ __forceinline__ int voxel_key(const GridF& gr, const float* c,
+                                         int64_t ib) {
+  const float fx = (c[0] - gr.lo[0]) / gr.step[0];
+  const float fy = (c[1] - gr.lo[1]) / gr.step[1];
+  const float fz = (c[2] - gr.lo[2]) / gr.step[2];
+  const long long ix = (long long)fx, iy = (long long)fy, iz = (long long)fz;
+  const bool ok = (ix >= 0) && ((float)ix < gr.size[0]) && (iy >= 0) &&
+                  ((float)iy < gr.size[1]) && (iz >= 0) &&
+                  ((float)iz < gr.size[2]);
+  if (!ok) return -1;
+  float r = (float)ib * (gr.size[2] * gr.size[1] * gr.size[0]);
+  r += (float)iz * (gr.size[1] * gr.size[0]);
+  r += (float)iy * gr.size[0] + (float)ix;
+  return (int)r;
+}
+
+template <bool FROM_COOR>
+__global__ __launch_bounds__(kBlock) void k_voxel_keys(
+    Geometry g, const float* __restrict__ coor, GridF gr, int N, int D, int H,
+    int W, int64_t P, int64_t n_bins, int* __restrict__ keys,
+    int* __restrict__ hist) {
+  const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (p >= P) return;
+  const int64_t per_b = (int64_t)N * D * H * W;
+  float c[3];
+  if (FROM_COOR) {
+    c[0] = coor[p * 3 + 0];
+    c[1] = coor[p * 3 + 1];
+    c[2] = coor[p * 3 + 2];
+  } else {
+    const int w = (int)(p % W);
+    const int h = (int)((p / W) % H);
+    const int d = (int)((p / ((int64_t)W * H)) % D);
+    const int bn = (int)(p / ((int64_t)W * H * D));
+    point_coor(g, bn, bn / N, d, h, w, c);
+  }
+  int key = voxel_key(gr, c, p / per_b);
+  if (key >= n_bins) key = -1;  // cannot happen for consistent grids; be safe
+  keys[p] = key;
+  if (key >= 0) atomicAdd(hist + key, 1);
+}
+
+// ---- exclusive scan over the histogram (count and non-empty flag) ----------
+struct Pair {
+  int pts;
+  int ivs;
+};
+
+__device__ __forceinline__ Pair block_reduce(Pair v, Pair* sm) {
+  for (int off = 32; off > 0; off >>= 1) {
+    v.pts += __shfl_down(v.pts, off);
+    v.ivs += __shfl_down(v.ivs, off);
+  }
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) sm[w] = v;
+  __syncthreads();
+  Pair t{0, 0};
+  if (threadIdx.x == 0) {
+    for (int i = 0; i < kBlock / 64; ++i) {
+      t.pts += sm[i].pts;
+      t.ivs += sm[i].ivs;
+    }
+  }
+  return t;  // valid in thread 0
+}
+
+__global__ __launch_bounds__(kBlock) void k_scan_reduce(
+    const int* __restrict__ hist, int64_t n_bins, Pair* __restrict__ block_sums) {
+  __shared__ Pair sm[kBlock / 64];
+  const int64_t base = (int64_t)blockIdx.x * kScanBlock + threadIdx.x * kScanItems;
+  Pair v{0, 0};
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) {
+    const int64_t i = base + k;
+    const int c = i < n_bins ? hist[i] : 0;
+    v.pts += c;
+    v.ivs += c > 0;
+  }
+  const Pair t = block_reduce(v, sm);
+  if (threadIdx.x == 0) block_sums[blockIdx.x] = t;
+}
+
+// single block: exclusive scan of the block sums in place; totals -> counts
+__global__ __launch_bounds__(kBlock) void k_scan_blocks(
+    Pair* __restrict__ block_sums, int n_blocks, int* __restrict__ counts) {
+  __shared__ Pair sm[kBlock];
+  Pair carry{0, 0};
+  for (int base = 0; base < n_blocks; base += kBlock) {
+    const int i = base + threadIdx.x;
+    Pair v = i < n_blocks ? block_sums[i] : Pair{0, 0};
+    sm[threadIdx.x] = v;
+    __syncthreads();
+    // Hillis-Steele inclusive scan in LDS
+    for (int off = 1; off < kBlock; off <<= 1) {
+      Pair add{0, 0};
+      if (threadIdx.x >= off) add = sm[threadIdx.x - off];
+      __syncthreads();
+      sm[threadIdx.x].pts += add.pts;
+      sm[threadIdx.x].ivs += add.ivs;
+      __syncthreads();
+    }
+    const Pair incl = sm[threadIdx.x];
+    if (i < n_blocks)
+      block_sums[i] = Pair{carry.pts + incl.pts - v.pts, carry.ivs + incl.ivs - v.ivs};
+    const Pair tot = sm[kBlock - 1];
+    __syncthreads();
+    carry.pts += tot.pts;
+    carry.ivs += tot.ivs;
+  }
+  if (threadIdx.x == 0) {
+    counts[0] = carry.pts;  // P_kept
+    counts[1] = carry.ivs;  // n_intervals
+  }
+}
+
+// per block: local exclusive scan + block offset; writes bin_start (in place of
+// nothing: separate array), the interval arrays and the plan entries of the
+// block's 16 tiles.
+__global__ __launch_bounds__(kBlock) void k_scan_emit(
+    const int* __restrict__ hist, int64_t n_bins, const Pair* __restrict__ block_sums,
+    int* __restrict__ bin_start, int* __restrict__ interval_starts,
+    int* __restrict__ interval_lengths, int4* __restrict__ plan,
+    int64_t vpb, int64_t tiles_per_batch) {
+  __shared__ Pair sm[kBlock];
+  const int64_t base = (int64_t)blockIdx.x * kScanBlock + threadIdx.x * kScanItems;
+  int c[kScanItems];
+  Pair v{0, 0};
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) {
+    const int64_t i = base + k;
+    c[k] = i < n_bins ? hist[i] : 0;
+    v.pts += c[k];
+    v.ivs += c[k] > 0;
+  }
+  sm[threadIdx.x] = v;
+  __syncthreads();
+  for (int off = 1; off < kBlock; off <<= 1) {
+    Pair add{0, 0};
+    if (threadIdx.x >= off) add = sm[threadIdx.x - off];
+    __syncthreads();
+    sm[threadIdx.x].pts += add.pts;
+    sm[threadIdx.x].ivs += add.ivs;
+    __syncthreads();
+  }
+  const Pair boff = block_sums[blockIdx.x];
+  Pair run{boff.pts + sm[threadIdx.x].pts - v.pts,
+           boff.ivs + sm[threadIdx.x].ivs - v.ivs};
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) {
+    const int64_t i = base + k;
+    if (i < n_bins) {
+      bin_start[i] = run.pts;
+      if (c[k] > 0) {
+        interval_starts[run.ivs] = run.pts;
+        interval_lengths[run.ivs] = c[k];
+      }
+    }
+    run.pts += c[k];
+    run.ivs += c[k] > 0;
+  }
+  // plan: tiles are 64 consecutive voxel ranks of ONE batch element.  When the
+  // voxel count per batch is a multiple of 64 (and so of the scan block's tile
+  // grid) a tile is 16 consecutive threads' bins.
+  if (plan != nullptr) {
+    // thread handles bins [base, base+4); tile = 16 threads
+    const int tl = threadIdx.x & 15;  // position inside the tile
+    // exclusive prefix at the tile's first thread and totals over the tile
+    const int first = threadIdx.x - tl;
+    const Pair pre{boff.pts + (first > 0 ? sm[first - 1].pts : 0),
+                   boff.ivs + (first > 0 ? sm[first - 1].ivs : 0)};
+    const Pair end{boff.pts + sm[first + 15].pts, boff.ivs + sm[first + 15].ivs};
+    if (tl == 0) {
+      const int64_t bin0 = (int64_t)blockIdx.x * kScanBlock + (int64_t)first * kScanItems;
+      if (bin0 < n_bins) {
+        const int64_t b = bin0 / vpb;
+        const int64_t t = b * tiles_per_batch + (bin0 - b * vpb) / kTileV;
+        plan[t] = make_int4(pre.ivs, end.ivs - pre.ivs, pre.pts, end.pts - pre.pts);
+      }
+    }
+  }
+}
+
+// points -> slots of their voxel (order inside the voxel fixed by k_rank_in_bin)
+__global__ __launch_bounds__(kBlock) void k_scatter(
+    const int* __restrict__ keys, int64_t P, const int* __restrict__ bin_start,
+    int* __restrict__ cursor, int* __restrict__ tmp_point) {
+  const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (p >= P) return;
+  const int key = keys[p];
+  if (key < 0) return;
+  const int slot = bin_start[key] + atomicAdd(cursor + key, 1);
+  tmp_point[slot] = (int)p;
+}
+
+// stable order inside each interval: final slot = start + #points of the
+// interval with a smaller index.  One lane per kept point.
+__global__ __launch_bounds__(kBlock) void k_rank_in_bin(
+    const int* __restrict__ keys, const int* __restrict__ tmp_point,
+    const int* __restrict__ counts, const int* __restrict__ bin_start,
+    const int* __restrict__ hist, int D, int HW, int* __restrict__ ranks_bev,
+    int* __restrict__ ranks_depth, int* __restrict__ ranks_feat) {
+  const int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (q >= counts[0]) return;
+  const int p = tmp_point[q];
+  const int key = keys[p];
+  const int start = bin_start[key];
+  const int len = hist[key];
+  int rank = 0;
+  for (int i = 0; i < len; ++i) rank += tmp_point[start + i] < p;
+  const int slot = start + rank;
+  ranks_bev[slot] = key;
+  ranks_depth[slot] = p;
+  // pixel index (b,n,h,w) of point (b,n,d,h,w): view_transformer_raw.py:262-265
+  ranks_feat[slot] = (p / (D * HW)) * HW + p % HW;
+}
+
+inline int launch_status() {
+  return hipGetLastError() == hipSuccess ? VEON_OK : VEON_ERR_LAUNCH;
+}
+
+struct Workspace {
+  int* keys;       // [P]
+  int* tmp_point;  // [P]
+  int* hist;       // [n_bins]      (zeroed per call)
+  int* cursor;     // [n_bins]      (zeroed per call; contiguous with hist)
+  int* bin_start;  // [n_bins]
+  Pair* block_sums;  // [n_scan_blocks]
+  int64_t bytes;
+};
+
+inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+
+inline Workspace carve(void* base, int64_t P, int64_t n_bins) {
+  Workspace w;
+  char* p = static_cast<char*>(base);
+  int64_t off = 0;
+  auto take = [&](int64_t bytes) {
+    char* r = p ? p + off : nullptr;
+    off += align_up(bytes, 256);
+    return r;
+  };
+  w.keys = reinterpret_cast<int*>(take(P * 4));
+  w.tmp_point = reinterpret_cast<int*>(take(P * 4));
+  w.hist = reinterpret_cast<int*>(take(n_bins * 4 * 2));
+  w.cursor = w.hist ? w.hist + n_bins : nullptr;
+  w.bin_start = reinterpret_cast<int*>(take(n_bins * 4));
+  const int64_t n_scan_blocks = (n_bins + kScanBlock - 1) / kScanBlock;
+  w.block_sums = reinterpret_cast<Pair*>(take(n_scan_blocks * (int64_t)sizeof(Pair)));
+  w.bytes = off;
+  return w;
+}
+
+}  // namespace
+
+extern "C" {
+
+int veon_camera_matrices(int BN, const float* sensor2ego, const float* cam2imgs,
+                         const float* post_rots, float* post_rots_inv,
+                         float* combine, float* trans, void* stream) {
+  if (BN <= 0 || !sensor2ego || !cam2imgs || !post_rots || !post_rots_inv ||
+      !combine || !trans)
+    return VEON_ERR_BAD_ARG;
+  hipLaunchKernelGGL(k_camera_matrices, dim3((BN + kBlock - 1) / kBlock),
+                     dim3(kBlock), 0, static_cast<hipStream_t>(stream), BN,
+                     sensor2ego, cam2imgs, post_rots, post_rots_inv, combine,
+                     trans);
+  return launch_status();
+}
+
+int veon_lidar_coor(int B, int N, int D, int H, int W, const float* xs,
+                    const float* ys, const float* ds,
+                    const float* post_rots_inv, const float* post_trans,
+                    const float* combine, const float* trans, const float* bda,
+                    float* coor, void* stream) {
+  if (B <= 0 || N <= 0 || D <= 0 || H <= 0 || W <= 0) return VEON_ERR_BAD_ARG;
+  if (!xs || !ys || !ds || !post_rots_inv || !post_trans || !combine || !trans ||
+      !bda || !coor)
+    return VEON_ERR_BAD_ARG;
+  const int64_t P = (int64_t)B * N * D * H * W;
+  if (P > 0x7fffffffLL) return VEON_ERR_BAD_ARG;
+  Geometry g{xs, ys, ds, post_rots_inv, post_trans, combine, trans, bda};
+  hipLaunchKernelGGL(k_lidar_coor, dim3((unsigned)((P + kBlock - 1) / kBlock)),
+                     dim3(kBlock), 0, static_cast<hipStream_t>(stream), g, N, D,
+                     H, W, P, coor);
+  return launch_status();
+}
+
+int64_t veon_lss_prepare_workspace_bytes(int64_t num_points,
+                                         int64_t num_voxels_total) {
+  if (num_points <= 0 || num_voxels_total <= 0) return 0;
+  return carve(nullptr, num_points, num_voxels_total).bytes;
+}
+
+int veon_lss_prepare(int B, int N, int D, int H, int W, const float* coor,
+                     const float* xs, const float* ys, const float* ds,
+                     const float* post_rots_inv, const float* post_trans,
+                     const float* combine, const float* trans, const float* bda,
+                     const float* grid_lower, const float* grid_interval,
+                     const float* grid_size, int64_t voxels_per_batch,
+                     void* workspace, int64_t workspace_bytes, int* ranks_bev,
+                     int* ranks_depth, int* ranks_feat, int* interval_starts,
+                     int* interval_lengths, int* plan, int* counts,
+                     void* stream) {
+  if (B <= 0 || N <= 0 || D <= 0 || H <= 0 || W <= 0 || voxels_per_batch <= 0)
+    return VEON_ERR_BAD_ARG;
+  if (!grid_lower || !grid_interval || !grid_size || !workspace || !ranks_bev ||
+      !ranks_depth || !ranks_feat || !interval_starts || !interval_lengths ||
+      !counts)
+    return VEON_ERR_BAD_ARG;
+  if (!coor && (!xs || !ys || !ds || !post_rots_inv || !post_trans || !combine ||
+                !trans || !bda))
+    return VEON_ERR_BAD_ARG;
+  const int64_t P = (int64_t)B * N * D * H * W;
+  const int64_t n_bins = voxels_per_batch * B;
+  if (P > 0x7fffffffLL || n_bins > 0x7fffffffLL) return VEON_ERR_BAD_ARG;
+  // the plan emitted by the scan needs tiles aligned to the scan blocks
+  if (plan && (voxels_per_batch % kTileV != 0)) return VEON_ERR_BAD_ARG;
+  if (plan && (reinterpret_cast<uintptr_t>(plan) & 15u)) return VEON_ERR_BAD_ARG;
+  const Workspace w = carve(workspace, P, n_bins);
+  if (w.bytes > workspace_bytes) return VEON_ERR_WORKSPACE;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  GridF gr;
+  for (int i = 0; i < 3; ++i) {
+    gr.lo[i] = grid_lower[i];
+    gr.step[i] = grid_interval[i];
+    gr.size[i] = grid_size[i];
+  }
+  Geometry g{xs, ys, ds, post_rots_inv, post_trans, combine, trans, bda};
+  if (hipMemsetAsync(w.hist, 0, (size_t)n_bins * 8, s) != hipSuccess)
+    return VEON_ERR_LAUNCH;
+  const unsigned pb = (unsigned)((P + kBlock - 1) / kBlock);
+  if (coor)
+    hipLaunchKernelGGL(k_voxel_keys<true>, dim3(pb), dim3(kBlock), 0, s, g, coor,
+                       gr, N, D, H, W, P, n_bins, w.keys, w.hist);
+  else
+    hipLaunchKernelGGL(k_voxel_keys<false>, dim3(pb), dim3(kBlock), 0, s, g,
+                       coor, gr, N, D, H, W, P, n_bins, w.keys, w.hist);
+  const int n_scan_blocks = (int)((n_bins + kScanBlock - 1) / kScanBlock);
+  hipLaunchKernelGGL(k_scan_reduce, dim3(n_scan_blocks), dim3(kBlock), 0, s,
+                     w.hist, n_bins, w.block_sums);
+  hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(kBlock), 0, s, w.block_sums,
+                     n_scan_blocks, counts);
+  const int64_t tiles_per_batch = voxels_per_batch / kTileV;
+  hipLaunchKernelGGL(k_scan_emit, dim3(n_scan_blocks), dim3(kBlock), 0, s,
+                     w.hist, n_bins, w.block_sums, w.bin_start, interval_starts,
+                     interval_lengths, reinterpret_cast<int4*>(plan),
+                     voxels_per_batch, tiles_per_batch);
+  hipLaunchKernelGGL(k_scatter, dim3(pb), dim3(kBlock), 0, s, w.keys, P,
+                     w.bin_start, w.cursor, w.tmp_point);
+  hipLaunchKernelGGL(k_rank_in_bin, dim3(pb), dim3(kBlock), 0, s, w.keys,
+                     w.tmp_point, counts, w.bin_start, w.hist, D, H * W,
+                     ranks_bev, ranks_depth, ranks_feat);
+  return launch_status();
+}
+
+}  // extern "C"

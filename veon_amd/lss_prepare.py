@@ -109,3 +109,19 @@ def voxel_pooling_prepare_v2(coor, lower, interval, gsize):
         return _HIP_PREPARE.voxel_pooling_prepare_v2(coor, lower, interval,
                                                      gsize)
     return voxel_pooling_prepare_v2_torch(coor, lower, interval, gsize)
+
+
+def prepare_from_matrices(frustum, post_rots_inv, post_trans, combine, trans,
+                          bda, lower, interval, gsize):
+    """get_lidar_coor's per-point half + voxel_pooling_prepare_v2 in one go
+    (on a ROCm device the coordinates are never materialised)."""
+    if combine.is_cuda and _HIP_PREPARE is not None:
+        return _HIP_PREPARE.prepare_from_matrices(
+            frustum, post_rots_inv, post_trans, combine, trans, bda, lower,
+            interval, gsize)
+    coor = lidar_coor_from_matrices_torch(frustum, post_rots_inv, post_trans,
+                                          combine, trans, bda)
+    return voxel_pooling_prepare_v2_torch(coor, lower, interval, gsize)
+
+
+from . import lss_prepare_hip  # noqa: E402,F401  (registers the device path)

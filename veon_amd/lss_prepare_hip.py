@@ -1,0 +1,172 @@
+"""HIP implementation of the index half (csrc/lss_prepare.hip) behind
+``veon_amd.lss_prepare``; imported for its side effect of registering itself as
+the device path.  Raises if libveon_hip.so is missing (no fallback)."""
+import ctypes
+
+import torch
+
+from . import _lib, lss_prepare
+from .ops.bev_pool_v2.bev_pool import mark_sorted
+
+_F3 = ctypes.c_float * 3
+
+
+def _axes(frustum, device):
+    """Device copies of the frustum axes xs[W], ys[H], ds[D], cached on the
+    (CPU) frustum tensor object."""
+    cache = getattr(frustum, '_veon_axes', None)
+    if cache is None:
+        cache = {}
+        frustum._veon_axes = cache
+    key = str(device)
+    if key not in cache:
+        fr = frustum.detach().float().cpu()
+        cache[key] = (fr[0, 0, :, 0].contiguous().to(device),
+                      fr[0, :, 0, 1].contiguous().to(device),
+                      fr[:, 0, 0, 2].contiguous().to(device))
+    return cache[key]
+
+
+def _f32c(t):
+    return t.contiguous().float()
+
+
+def lidar_coor_from_matrices(frustum, post_rots_inv, post_trans, combine, trans,
+                             bda):
+    dev = _lib.require_device(post_rots_inv, post_trans, combine, trans, bda)
+    B, N = combine.shape[:2]
+    D, H, W, _ = frustum.shape
+    xs, ys, ds = _axes(frustum, dev)
+    pri, pt, cb, tr, bd = (_f32c(t) for t in (post_rots_inv, post_trans, combine,
+                                              trans, bda))
+    coor = torch.empty((B, N, D, H, W, 3), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        st = _lib.lib().veon_lidar_coor(
+            B, N, D, H, W, _lib.ptr(xs), _lib.ptr(ys), _lib.ptr(ds),
+            _lib.ptr(pri), _lib.ptr(pt), _lib.ptr(cb), _lib.ptr(tr),
+            _lib.ptr(bd), _lib.ptr(coor), _lib.stream_ptr(dev))
+    _lib.check(st, 'veon_lidar_coor')
+    return coor
+
+
+def camera_matrices(sensor2ego, cam2imgs, post_rots):
+    """Stream-capturable camera algebra (csrc k_camera_matrices)."""
+    dev = _lib.require_device(sensor2ego, cam2imgs, post_rots)
+    B, N = sensor2ego.shape[:2]
+    s2e, k, pr = _f32c(sensor2ego), _f32c(cam2imgs), _f32c(post_rots)
+    pri = torch.empty((B, N, 3, 3), dtype=torch.float32, device=dev)
+    comb = torch.empty((B, N, 3, 3), dtype=torch.float32, device=dev)
+    trans = torch.empty((B, N, 3), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        st = _lib.lib().veon_camera_matrices(
+            B * N, _lib.ptr(s2e), _lib.ptr(k), _lib.ptr(pr), _lib.ptr(pri),
+            _lib.ptr(comb), _lib.ptr(trans), _lib.stream_ptr(dev))
+    _lib.check(st, 'veon_camera_matrices')
+    return pri, comb, trans
+
+
+class Prepared:
+    """Full-capacity device buffers of one prepare call (no host sync yet)."""
+    __slots__ = ('ranks_bev', 'ranks_depth', 'ranks_feat', 'interval_starts',
+                 'interval_lengths', 'plan', 'counts', 'batch', 'vpb')
+
+
+def _grid_host(lower, interval, gsize):
+    return (_F3(*[float(v) for v in lower.tolist()]),
+            _F3(*[float(v) for v in interval.tolist()]),
+            _F3(*[float(v) for v in gsize.tolist()]))
+
+
+def _vpb(gsize):
+    return int(gsize[2]) * int(gsize[1]) * int(gsize[0])
+
+
+def prepare_device(dims, coor, geometry, lower, interval, gsize, device):
+    """Launch the prepare pipeline; returns ``Prepared`` (capacity-sized
+    buffers + device counts).  ``geometry`` = (frustum, pri, post_trans,
+    combine, trans, bda) when ``coor`` is None."""
+    B, N, D, H, W = dims
+    L = _lib.lib()
+    P = B * N * D * H * W
+    vpb = _vpb(gsize)
+    ws_bytes = L.veon_lss_prepare_workspace_bytes(P, vpb * B)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
+    out = Prepared()
+    out.batch, out.vpb = B, vpb
+    out.ranks_bev = torch.empty(P, dtype=torch.int32, device=device)
+    out.ranks_depth = torch.empty(P, dtype=torch.int32, device=device)
+    out.ranks_feat = torch.empty(P, dtype=torch.int32, device=device)
+    out.interval_starts = torch.empty(P, dtype=torch.int32, device=device)
+    out.interval_lengths = torch.empty(P, dtype=torch.int32, device=device)
+    out.counts = torch.empty(2, dtype=torch.int32, device=device)
+    out.plan = None
+    if vpb % 64 == 0:
+        out.plan = torch.empty(L.veon_bev_pool_plan_ints(B, vpb),
+                               dtype=torch.int32, device=device)
+    glo, gstep, gsz = _grid_host(lower, interval, gsize)
+    null = ctypes.c_void_p(0)
+    if coor is not None:
+        geo = [null] * 8
+        coor_p = _lib.ptr(coor)
+        keep = (coor,)
+    else:
+        frustum, pri, pt, cb, tr, bd = geometry
+        xs, ys, ds = _axes(frustum, device)
+        keep = tuple(_f32c(t) for t in (pri, pt, cb, tr, bd)) + (xs, ys, ds)
+        geo = [_lib.ptr(xs), _lib.ptr(ys), _lib.ptr(ds)] + \
+            [_lib.ptr(t) for t in keep[:5]]
+        coor_p = null
+    with torch.cuda.device(device):
+        st = L.veon_lss_prepare(
+            B, N, D, H, W, coor_p, *geo,
+            ctypes.cast(glo, ctypes.c_void_p), ctypes.cast(gstep, ctypes.c_void_p),
+            ctypes.cast(gsz, ctypes.c_void_p), vpb, _lib.ptr(ws), ws_bytes,
+            _lib.ptr(out.ranks_bev), _lib.ptr(out.ranks_depth),
+            _lib.ptr(out.ranks_feat), _lib.ptr(out.interval_starts),
+            _lib.ptr(out.interval_lengths), _lib.ptr(out.plan),
+            _lib.ptr(out.counts), _lib.stream_ptr(device))
+    _lib.check(st, 'veon_lss_prepare')
+    del keep
+    return out
+
+
+def _finish(pre):
+    """The reference contract: exactly-sized tensors (one host sync, as the
+    reference's own torch.where / len() calls), or 5 x None when empty."""
+    kept, n_int = (int(v) for v in pre.counts.tolist())
+    if kept == 0 or n_int == 0:
+        return None, None, None, None, None
+    rb = pre.ranks_bev[:kept]
+    starts = pre.interval_starts[:n_int]
+    # first / last rank are only needed for the bounds tag: they are inside the
+    # grid by construction
+    mark_sorted(starts, 0, pre.batch * pre.vpb - 1)
+    if pre.plan is not None:
+        starts._veon_plan = (pre.plan, pre.batch, pre.vpb)
+    return (rb, pre.ranks_depth[:kept], pre.ranks_feat[:kept], starts,
+            pre.interval_lengths[:n_int])
+
+
+def voxel_pooling_prepare_v2(coor, lower, interval, gsize):
+    dev = _lib.require_device(coor)
+    B, N, D, H, W, _ = coor.shape
+    pre = prepare_device((B, N, D, H, W), _f32c(coor), None, lower, interval,
+                         gsize, dev)
+    return _finish(pre)
+
+
+def prepare_from_matrices(frustum, post_rots_inv, post_trans, combine, trans,
+                          bda, lower, interval, gsize, sync=True):
+    """Geometry fused into the prepare (coordinates never materialised)."""
+    dev = _lib.require_device(post_rots_inv, post_trans, combine, trans, bda)
+    B, N = combine.shape[:2]
+    D, H, W, _ = frustum.shape
+    pre = prepare_device((B, N, D, H, W), None,
+                         (frustum, post_rots_inv, post_trans, combine, trans, bda),
+                         lower, interval, gsize, dev)
+    return _finish(pre) if sync else pre
+
+
+import sys  # noqa: E402
+
+lss_prepare._HIP_PREPARE = sys.modules[__name__]

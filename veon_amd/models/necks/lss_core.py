@@ -43,6 +43,12 @@ class LSSCore(_Base):
         self.accelerate = accelerate
         self.initial_flag = True
         self.collapse_z = collapse_z
+        # veon_amd extension (default off = the reference's exact behaviour):
+        # run the per-call prepare without any host sync (inference only; an
+        # empty grid then yields zeros of the regular shape instead of the
+        # reference's odd-shaped dummy).  Makes accelerate=False capturable in
+        # a hipGraph.
+        self.sync_free = False
 
     # ------------------------------------------------------------------ grid
     def create_grid_infos(self, x, y, z, **kwargs):
@@ -136,6 +142,21 @@ class LSSCore(_Base):
             bev_feat = torch.cat(bev_feat.unbind(dim=2), 1)
         return bev_feat
 
+    def _lift_sync_free(self, input, depth, feat):
+        sensor2ego, _, cam2imgs, post_rots, post_trans, bda = input[1:7]
+        pri, comb, trans = _prep._HIP_PREPARE.camera_matrices(
+            sensor2ego, cam2imgs, post_rots)
+        pre = _prep._HIP_PREPARE.prepare_from_matrices(
+            self.frustum, pri, post_trans, comb, trans, bda,
+            self.grid_lower_bound, self.grid_interval, self.grid_size,
+            sync=False)
+        bev_feat = _bp.bev_pool_v2_prepared(
+            depth, feat.permute(0, 1, 3, 4, 2), pre,
+            self._bev_feat_shape(depth.shape[0], feat.shape[2]))
+        if self.collapse_z:
+            bev_feat = torch.cat(bev_feat.unbind(dim=2), 1)
+        return bev_feat
+
     # ---------------------------------------------------------- entry points
     def pre_compute(self, input):
         if self.initial_flag:
@@ -154,6 +175,11 @@ class LSSCore(_Base):
                 self._bev_feat_shape(B, feat.shape[-1]), self.interval_starts,
                 self.interval_lengths)
             bev_feat = bev_feat.squeeze(2)
+        elif (self.sync_free and tran_feat.is_cuda
+              and not torch.is_grad_enabled()):
+            bev_feat = self._lift_sync_free(
+                input, depth.view(B, N, self.D, H, W),
+                tran_feat.view(B, N, self.out_channels, H, W))
         else:
             coor = self.get_lidar_coor(*input[1:7])
             bev_feat = self.voxel_pooling_v2(

@@ -216,6 +216,31 @@ def bev_pool_v2(depth, feat, ranks_depth, ranks_feat, ranks_bev,
     return x.permute(0, 4, 1, 2, 3).contiguous()
 
 
+def bev_pool_v2_prepared(depth, feat, pre, bev_feat_shape):
+    """Inference-only pooling straight from the device-resident output of the
+    HIP prepare (``lss_prepare_hip.Prepared``): capacity-sized rank buffers and
+    the plan the prepare emitted, no host synchronisation anywhere -- the whole
+    per-call lift is hipGraph-capturable.  The plan alone drives the fused
+    kernel, so the (unknown on the host) point / interval counts are not needed.
+    An empty grid yields an all-zero (B,C,Z,Y,X) volume."""
+    depth = depth.contiguous().float()
+    feat = feat.contiguous().float()
+    B, Z, Y, X, C = [int(s) for s in bev_feat_shape]
+    if pre.plan is None or pre.batch != B or pre.vpb != Z * Y * X:
+        raise _lib.VeonHipError('prepared plan does not match bev_feat_shape')
+    dev = _lib.require_device(depth, feat, pre.ranks_bev)
+    out = torch.empty((B, C, Z, Y, X), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        st = _lib.lib().veon_bev_pool_v2_fwd_fused(
+            C, pre.interval_starts.numel(), B, Z * Y * X, _lib.ptr(depth),
+            _lib.ptr(feat), _lib.ptr(pre.ranks_depth), _lib.ptr(pre.ranks_feat),
+            _lib.ptr(pre.ranks_bev), _lib.ptr(pre.interval_starts),
+            _lib.ptr(pre.interval_lengths), _lib.ptr(pre.plan), _lib.ptr(out),
+            _lib.LAYOUT_BCZYX, _lib.stream_ptr(dev))
+    _lib.check(st, 'veon_bev_pool_v2_fwd_fused')
+    return out
+
+
 class TRTBEVPoolv2(torch.autograd.Function):
     """ONNX export shim, same symbolic as the reference (bev_pool.py:95-142)."""
 
