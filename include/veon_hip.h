@@ -76,7 +76,9 @@ int veon_bev_pool_v2_bwd(int c, int n_intervals, const float *out_grad,
  * aligned; the first 4*n_tiles are the entries, the rest is build scratch.
  * Build it once beside the five rank arrays when they are cached (the
  * accelerate=True path, view_transformer_raw.py:196-215), or per call
- * (two tiny kernels).  Requires the intervals ascending and unique in
+ * (two tiny kernels).  `counts` (optional DEVICE int[2] = {points, intervals})
+ * overrides n_points / n_intervals, which then only bound the launch.
+ * Requires the intervals ascending and unique in
  * ranks_bev[interval_starts[i]] -- what voxel_pooling_prepare_v2 produces
  * (view_transformer_raw.py:287-299).
  */
@@ -84,7 +86,8 @@ int veon_bev_pool_tile_voxels(void);
 int64_t veon_bev_pool_plan_ints(int batch, int64_t voxels_per_batch);
 int veon_bev_pool_plan(int n_intervals, int n_points, int batch,
                        int64_t voxels_per_batch, const int *ranks_bev,
-                       const int *interval_starts, int *plan, void *stream);
+                       const int *interval_starts, const int *counts, int *plan,
+                       void *stream);
 
 /*
  * Fused forward: zero-fill + pool (+ layout permute) in ONE pass; every
@@ -103,6 +106,34 @@ int veon_bev_pool_v2_fwd_fused(int c, int n_intervals, int batch,
                                const int *interval_starts,
                                const int *interval_lengths, const int *plan,
                                float *out, int out_layout, void *stream);
+
+/*
+ * Fused forward + max-pool: LSSViewTransformerRaw.forward's
+ * `bev_pool_v2` followed by the (dz,dy,dx) block max
+ * (view_transformer_raw.py:545-553) in one kernel; the full-resolution volume
+ * is never written.  out is (B, C, Z/dz, Y/dy, X/dx) fp32, every element
+ * written.  Bit-equal to max-pooling veon_bev_pool_v2_fwd_fused's output.
+ * row_first: veon_bev_pool_row_table(..., row_voxels = X, ...) -- first
+ * interval of every (b,z,y) row of X voxels, B*Z*Y+1 entries (row_point, same
+ * size, receives the first point of every row).  `counts` (optional DEVICE
+ * int[2] = {points, intervals}, e.g. veon_lss_prepare's) overrides
+ * n_points / n_intervals, which then only bound the launch (pass the buffer
+ * capacity).  Same preconditions as veon_bev_pool_plan.
+ */
+int veon_bev_pool_row_table(int n_intervals, int n_points, int batch,
+                            int64_t voxels_per_batch, int row_voxels,
+                            const int *ranks_bev, const int *interval_starts,
+                            const int *counts, int *row_first, int *row_point,
+                            void *stream);
+int veon_bev_pool_v2_fwd_maxpool(int c, int n_intervals, int batch, int Z, int Y,
+                                 int X, int dz, int dy, int dx,
+                                 const float *depth, const float *feat,
+                                 const int *ranks_depth, const int *ranks_feat,
+                                 const int *ranks_bev,
+                                 const int *interval_starts,
+                                 const int *interval_lengths,
+                                 const int *row_first, float *out,
+                                 void *stream);
 
 /*
  * The per-camera 3x3 algebra of get_lidar_coor

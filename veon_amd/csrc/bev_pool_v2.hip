@@ -152,12 +152,17 @@ constexpr int kTileV = 64;
 __global__ __launch_bounds__(kBlock) void k_plan_bounds(
     const int* __restrict__ ranks_bev, const int* __restrict__ interval_starts,
     int n_intervals, int n_points, int64_t vpb, int64_t tiles_per_batch,
-    int64_t n_tiles, int* __restrict__ tile_first, int* __restrict__ tile_point) {
+    int64_t n_tiles, int tile_voxels, int* __restrict__ tile_first,
+    int* __restrict__ tile_point, const int* __restrict__ counts) {
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (counts != nullptr) {  // sizes known only on the device (sync-free path)
+    n_points = counts[0];
+    n_intervals = counts[1];
+  }
   if (i > n_intervals) return;
   auto tile_of = [&](int rank) -> int64_t {
     const int64_t b = rank / vpb;
-    return b * tiles_per_batch + (rank - b * vpb) / kTileV;
+    return b * tiles_per_batch + (rank - b * vpb) / tile_voxels;
   };
   int64_t hi = n_tiles;
   int st = n_points;
@@ -425,6 +430,86 @@ __global__ __launch_bounds__(kBlock) void k_pool_fused_cf(
 }
 
 // ---------------------------------------------------------------------------
+// (4) Fused forward + (dz,dy,dx) max-pool, channels-first: what
+//     LSSViewTransformerRaw.forward computes (view_transformer_raw.py:537-555:
+//     bev_pool_v2 then rearrange + max over 2x2x2 blocks) without ever writing
+//     the full-resolution volume.  One workgroup = one pooled row (b, zo, yo)
+//     x one channel slab: the dz*dy input rows' intervals are summed exactly as
+//     above and folded into an LDS tile [cs][Xo] by integer atomic max on an
+//     order-preserving key (max is order independent, so the result is
+//     deterministic and bit-equal to max-pooling the full volume).  A pooled
+//     voxel with fewer than dz*dy*dx occupied inputs also competes against the
+//     zeros of its empty inputs.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int float_key(float f) {
+  const int b = __float_as_int(f);
+  return b ^ ((b >> 31) & 0x7fffffff);
+}
+__device__ __forceinline__ float key_float(int k) {
+  return __int_as_float(k ^ ((k >> 31) & 0x7fffffff));
+}
+
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void k_pool_maxpool_cf(
+    PoolArgs a, const int* __restrict__ row_first, int c, int cs, int Z, int Y,
+    int X, int dz, int dy, int dx, float* __restrict__ out) {
+  extern __shared__ int ldsi[];
+  const int Zo = Z / dz, Yo = Y / dy, Xo = X / dx;
+  int* tile = ldsi;            // [cs][Xo] keys
+  int* occ = ldsi + cs * Xo;   // [Xo] occupied input voxels per pooled voxel
+  const int tid = threadIdx.x;
+  const int64_t orow = blockIdx.x;  // (b, zo, yo)
+  const int yo = (int)(orow % Yo);
+  const int zo = (int)((orow / Yo) % Zo);
+  const int b = (int)(orow / ((int64_t)Yo * Zo));
+  const int c0 = blockIdx.y * cs;
+  const int nch = (c - c0) < cs ? (c - c0) : cs;
+  const int nq = nch / VEC;
+  const int kmin = float_key(-__builtin_inff());
+  for (int i = tid; i < cs * Xo; i += kBlock) tile[i] = kmin;
+  for (int i = tid; i < Xo; i += kBlock) occ[i] = 0;
+  __syncthreads();
+  using VT = typename Vec<VEC>::T;
+  for (int rz = 0; rz < dz; ++rz)
+    for (int ry = 0; ry < dy; ++ry) {
+      const int64_t row = ((int64_t)b * Z + (zo * dz + rz)) * Y + (yo * dy + ry);
+      const int64_t rank0 = row * X;
+      const int i0 = row_first[row];
+      const int cnt = row_first[row + 1] - i0;
+      const int items = cnt * nq;
+      for (int item = tid; item < items; item += kBlock) {
+        const int j = item / nq;
+        const int q = item - j * nq;
+        const int start = a.interval_starts[i0 + j];
+        const int len = a.interval_lengths[i0 + j];
+        const int xo = (int)((int64_t)a.ranks_bev[start] - rank0) / dx;
+        const VT acc = interval_sum<VEC>(a, c, start, len, c0 + q * VEC);
+        const float* ap = reinterpret_cast<const float*>(&acc);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k)
+          atomicMax(&tile[(q * VEC + k) * Xo + xo], float_key(ap[k]));
+        if (q == 0) atomicAdd(&occ[xo], 1);
+      }
+    }
+  __syncthreads();
+  const int full = dz * dy * dx;
+  float* obase =
+      out + ((((int64_t)b * c + c0) * Zo + zo) * Yo + yo) * (int64_t)Xo;
+  const int64_t cstride = (int64_t)Zo * Yo * Xo;
+  for (int i = tid; i < nch * Xo; i += kBlock) {
+    const int cc = i / Xo;
+    const int xo = i - cc * Xo;
+    const int n = occ[xo];
+    float v = 0.f;
+    if (n > 0) {
+      v = key_float(tile[cc * Xo + xo]);
+      if (n < full && !(v > 0.f)) v = 0.f;
+    }
+    obase[(int64_t)cc * cstride + xo] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------
 // (5) Backward.  One 128-thread block per interval of the feat-sorted list.
 //     phase A (bev_pool_cuda.cu:91-105): lanes = points of the interval, each
 //       runs the serial channel chain for depth_grad;
@@ -565,7 +650,8 @@ int64_t veon_bev_pool_plan_ints(int batch, int64_t voxels_per_batch) {
 
 int veon_bev_pool_plan(int n_intervals, int n_points, int batch,
                        int64_t voxels_per_batch, const int* ranks_bev,
-                       const int* interval_starts, int* plan, void* stream) {
+                       const int* interval_starts, const int* counts, int* plan,
+                       void* stream) {
   if (n_intervals < 0 || n_points < 0 || batch <= 0 || voxels_per_batch <= 0 ||
       !plan)
     return VEON_ERR_BAD_ARG;
@@ -581,10 +667,72 @@ int veon_bev_pool_plan(int n_intervals, int n_points, int batch,
   const unsigned b1 = (unsigned)(((int64_t)n_intervals + 1 + kBlock - 1) / kBlock);
   hipLaunchKernelGGL(k_plan_bounds, dim3(b1), dim3(kBlock), 0, s, ranks_bev,
                      interval_starts, n_intervals, n_points, voxels_per_batch,
-                     tiles_per_batch, n_tiles, tile_first, tile_point);
+                     tiles_per_batch, n_tiles, kTileV, tile_first, tile_point, counts);
   const unsigned b2 = (unsigned)((n_tiles + kBlock - 1) / kBlock);
   hipLaunchKernelGGL(k_plan_pack, dim3(b2), dim3(kBlock), 0, s, tile_first,
                      tile_point, n_tiles, reinterpret_cast<int4*>(plan));
+  return launch_status();
+}
+
+int veon_bev_pool_row_table(int n_intervals, int n_points, int batch,
+                            int64_t voxels_per_batch, int row_voxels,
+                            const int* ranks_bev, const int* interval_starts,
+                            const int* counts, int* row_first, int* row_point,
+                            void* stream) {
+  if (n_intervals < 0 || n_points < 0 || batch <= 0 || voxels_per_batch <= 0 ||
+      row_voxels <= 0 || voxels_per_batch % row_voxels != 0 || !row_first ||
+      !row_point)
+    return VEON_ERR_BAD_ARG;
+  if (n_intervals > 0 && (!ranks_bev || !interval_starts))
+    return VEON_ERR_BAD_ARG;
+  const int64_t rows_per_batch = voxels_per_batch / row_voxels;
+  const int64_t n_rows = rows_per_batch * batch;
+  if (n_rows > 0x3fffffffLL) return VEON_ERR_BAD_ARG;
+  const unsigned b1 = (unsigned)(((int64_t)n_intervals + 1 + kBlock - 1) / kBlock);
+  hipLaunchKernelGGL(k_plan_bounds, dim3(b1), dim3(kBlock), 0,
+                     static_cast<hipStream_t>(stream), ranks_bev,
+                     interval_starts, n_intervals, n_points, voxels_per_batch,
+                     rows_per_batch, n_rows, row_voxels, row_first, row_point, counts);
+  return launch_status();
+}
+
+int veon_bev_pool_v2_fwd_maxpool(int c, int n_intervals, int batch, int Z, int Y,
+                                 int X, int dz, int dy, int dx,
+                                 const float* depth, const float* feat,
+                                 const int* ranks_depth, const int* ranks_feat,
+                                 const int* ranks_bev,
+                                 const int* interval_starts,
+                                 const int* interval_lengths,
+                                 const int* row_first, float* out,
+                                 void* stream) {
+  if (c <= 0 || n_intervals < 0 || batch <= 0 || Z <= 0 || Y <= 0 || X <= 0 ||
+      dz <= 0 || dy <= 0 || dx <= 0 || Z % dz || Y % dy || X % dx || !out ||
+      !row_first)
+    return VEON_ERR_BAD_ARG;
+  if (n_intervals > 0 &&
+      (!depth || !feat || !ranks_depth || !ranks_feat || !ranks_bev ||
+       !interval_starts || !interval_lengths))
+    return VEON_ERR_BAD_ARG;
+  if ((int64_t)batch * Z * Y * X > 0x7fffffffLL) return VEON_ERR_BAD_ARG;
+  PoolArgs a{depth, feat, ranks_depth, ranks_feat, ranks_bev, interval_starts,
+             interval_lengths};
+  const int Xo = X / dx;
+  // channel slab so that the [cs][Xo] key tile stays <= 32 KB
+  int cs = c;
+  while ((int64_t)cs * Xo * 4 > 32768 && cs > 4) cs = (cs / 2 + 3) / 4 * 4;
+  const int slabs = (c + cs - 1) / cs;
+  const bool v4 = (c % 4 == 0) && (cs % 4 == 0) && aligned16(feat);
+  const size_t lds = ((size_t)cs * Xo + Xo) * sizeof(int);
+  const int64_t orows = (int64_t)batch * (Z / dz) * (Y / dy);
+  if (orows > 0x7fffffffLL) return VEON_ERR_BAD_ARG;
+  const dim3 grid((unsigned)orows, (unsigned)slabs);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (v4)
+    hipLaunchKernelGGL(k_pool_maxpool_cf<4>, grid, dim3(kBlock), lds, s, a,
+                       row_first, c, cs, Z, Y, X, dz, dy, dx, out);
+  else
+    hipLaunchKernelGGL(k_pool_maxpool_cf<1>, grid, dim3(kBlock), lds, s, a,
+                       row_first, c, cs, Z, Y, X, dz, dy, dx, out);
   return launch_status();
 }
 

@@ -116,6 +116,8 @@ class LSSCore(_Base):
         vpb = int(self.grid_size[2]) * int(self.grid_size[1]) * \
             int(self.grid_size[0])
         _bp.build_plan(self.ranks_bev, self.interval_starts, B, vpb)
+        _bp.build_row_table(self.ranks_bev, self.interval_starts, B, vpb,
+                            int(self.grid_size[0]))
 
     def _bev_feat_shape(self, B, C):
         return (B, int(self.grid_size[2]), int(self.grid_size[1]),
@@ -156,6 +158,38 @@ class LSSCore(_Base):
         if self.collapse_z:
             bev_feat = torch.cat(bev_feat.unbind(dim=2), 1)
         return bev_feat
+
+    def _lift_maxpool(self, input, depth, feat, ds):
+        """forward's pool + (dz,dy,dx) block max in one kernel (inference).
+        depth (B,N,D,H,W), feat (B,N,C,H,W) -> (B,C,Z/dz,Y/dy,X/dx)."""
+        B = depth.shape[0]
+        shape = self._bev_feat_shape(B, feat.shape[2])
+        feat = feat.permute(0, 1, 3, 4, 2)
+        if self.accelerate:
+            self.pre_compute(input)
+            return _bp.bev_pool_v2_maxpool(
+                depth, feat, self.ranks_depth, self.ranks_feat, self.ranks_bev,
+                shape, self.interval_starts, self.interval_lengths, ds)
+        sensor2ego, _, cam2imgs, post_rots, post_trans, bda = input[1:7]
+        if self.sync_free:
+            pri, comb, trans = _prep._HIP_PREPARE.camera_matrices(
+                sensor2ego, cam2imgs, post_rots)
+            pre = _prep._HIP_PREPARE.prepare_from_matrices(
+                self.frustum, pri, post_trans, comb, trans, bda,
+                self.grid_lower_bound, self.grid_interval, self.grid_size,
+                sync=False)
+            return _bp.bev_pool_v2_maxpool(
+                depth, feat, pre.ranks_depth, pre.ranks_feat, pre.ranks_bev,
+                shape, pre.interval_starts, pre.interval_lengths, ds,
+                counts=pre.counts)
+        pri, comb, trans = _prep.camera_matrices(sensor2ego, cam2imgs, post_rots)
+        ranks = _prep.prepare_from_matrices(
+            self.frustum, pri, post_trans, comb, trans, bda,
+            self.grid_lower_bound, self.grid_interval, self.grid_size)
+        if ranks[0] is None:
+            return None
+        rb, rd, rf, st, ln = ranks
+        return _bp.bev_pool_v2_maxpool(depth, feat, rd, rf, rb, shape, st, ln, ds)
 
     # ---------------------------------------------------------- entry points
     def pre_compute(self, input):

@@ -36,6 +36,10 @@ class LSSViewTransformerRaw(LSSCore):
         assert len(self.ds) == 3
         self.use_ds = any(x != 1 for x in self.ds)
         assert self.mode in ['nuscenes']
+        # veon_amd extension: fold the ds_feat max-pool into the pool kernel at
+        # inference (bit-equal result; the full-resolution volume is never
+        # written).  Set False to run the reference's two-step structure.
+        self.fuse_ds = True
 
     # ------------------------------------------------------------ depth prep
     def downsample_depth(self, depths, downsample):
@@ -92,6 +96,13 @@ class LSSViewTransformerRaw(LSSCore):
                                       reduction='none').sum() / max(1.0, fg.sum())
         return self.loss_depth_weight * loss
 
+    def _can_fuse_ds(self, feat):
+        if not (self.use_ds and self.fuse_ds and feat.is_cuda
+                and not self.collapse_z and not torch.is_grad_enabled()):
+            return False
+        x, y, z = (int(v) for v in self.grid_size)
+        return z % self.ds[0] == 0 and y % self.ds[1] == 0 and x % self.ds[2] == 0
+
     # ---------------------------------------------------------------- forward
     def forward(self, input, depth, stereo_metas=None):
         """input = (tran_feat (B,N,C,Hf,Wf), sensor2ego, ego2global, intrins,
@@ -100,6 +111,11 @@ class LSSViewTransformerRaw(LSSCore):
         (:537-555)."""
         tran_feat = input[0]
         B, N, C, H, W = tran_feat.shape
+        if self._can_fuse_ds(tran_feat):
+            out = self._lift_maxpool(input, depth.view(B, N, self.D, H, W),
+                                     tran_feat, self.ds)
+            if out is not None:
+                return out
         tran_feat = tran_feat.view(B * N, C, H, W)
         depth = depth.view(B * N, depth.shape[2], H, W)
         bev_feat = self.view_transform(input, depth, tran_feat)

@@ -73,7 +73,7 @@ def _prep_inputs(depth, feat, ranks_depth, ranks_feat, ranks_bev,
 
 
 def build_plan(ranks_bev, interval_starts, batch, voxels_per_batch,
-               attach=True):
+               attach=True, counts=None):
     """Per-tile plan of the fused kernels (include/veon_hip.h
     ``veon_bev_pool_plan``).  With ``attach`` it is cached on
     ``interval_starts`` -- do that when the ranks themselves are cached
@@ -86,7 +86,7 @@ def build_plan(ranks_bev, interval_starts, batch, voxels_per_batch,
         st = L.veon_bev_pool_plan(
             interval_starts.numel(), ranks_bev.numel(), batch,
             voxels_per_batch, _lib.ptr(ranks_bev), _lib.ptr(interval_starts),
-            _lib.ptr(plan), _lib.stream_ptr(dev))
+            _lib.ptr(counts), _lib.ptr(plan), _lib.stream_ptr(dev))
     _lib.check(st, 'veon_bev_pool_plan')
     if attach:
         interval_starts._veon_plan = (plan, batch, voxels_per_batch)
@@ -226,8 +226,11 @@ def bev_pool_v2_prepared(depth, feat, pre, bev_feat_shape):
     depth = depth.contiguous().float()
     feat = feat.contiguous().float()
     B, Z, Y, X, C = [int(s) for s in bev_feat_shape]
-    if pre.plan is None or pre.batch != B or pre.vpb != Z * Y * X:
-        raise _lib.VeonHipError('prepared plan does not match bev_feat_shape')
+    if pre.batch != B or pre.vpb != Z * Y * X:
+        raise _lib.VeonHipError('prepared ranks do not match bev_feat_shape')
+    if pre.plan is None:  # voxel count not a multiple of the tile: build it now
+        pre.plan = build_plan(pre.ranks_bev, pre.interval_starts, B, Z * Y * X,
+                              attach=False, counts=pre.counts)
     dev = _lib.require_device(depth, feat, pre.ranks_bev)
     out = torch.empty((B, C, Z, Y, X), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
@@ -238,6 +241,58 @@ def bev_pool_v2_prepared(depth, feat, pre, bev_feat_shape):
             _lib.ptr(pre.interval_lengths), _lib.ptr(pre.plan), _lib.ptr(out),
             _lib.LAYOUT_BCZYX, _lib.stream_ptr(dev))
     _lib.check(st, 'veon_bev_pool_v2_fwd_fused')
+    return out
+
+
+def build_row_table(ranks_bev, interval_starts, batch, voxels_per_batch,
+                    row_voxels, counts=None, attach=True):
+    """First interval of every (b,z,y) row of X voxels, for the fused
+    pool+max-pool kernel (include/veon_hip.h ``veon_bev_pool_row_table``)."""
+    dev = _lib.require_device(ranks_bev, interval_starts)
+    n_rows = batch * (voxels_per_batch // row_voxels)
+    table = torch.empty(2 * (n_rows + 1), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        st = _lib.lib().veon_bev_pool_row_table(
+            interval_starts.numel(), ranks_bev.numel(), batch, voxels_per_batch,
+            row_voxels, _lib.ptr(ranks_bev), _lib.ptr(interval_starts),
+            _lib.ptr(counts), _lib.ptr(table), _lib.ptr(table[n_rows + 1:]),
+            _lib.stream_ptr(dev))
+    _lib.check(st, 'veon_bev_pool_row_table')
+    if attach:
+        interval_starts._veon_rows = (table, batch, voxels_per_batch, row_voxels)
+    return table
+
+
+def bev_pool_v2_maxpool(depth, feat, ranks_depth, ranks_feat, ranks_bev,
+                        bev_feat_shape, interval_starts, interval_lengths, ds,
+                        counts=None):
+    """Inference-only fusion of ``bev_pool_v2`` with the (dz,dy,dx) block max of
+    LSSViewTransformerRaw.forward (view_transformer_raw.py:545-553): returns
+    (B, C, Z/dz, Y/dy, X/dx) without writing the full-resolution volume.
+    Bit-equal to max-pooling ``bev_pool_v2``'s output.  Intervals must be
+    ascending in voxel rank (what the prepare produces)."""
+    depth = depth.contiguous().float()
+    feat = feat.contiguous().float()
+    B, Z, Y, X, C = [int(s) for s in bev_feat_shape]
+    dz, dy, dx = [int(v) for v in ds]
+    dev = _lib.require_device(depth, feat, ranks_depth, ranks_feat, ranks_bev,
+                              interval_starts, interval_lengths)
+    rows = getattr(interval_starts, '_veon_rows', None)
+    if counts is None and rows is not None and rows[1:] == (B, Z * Y * X, X):
+        table = rows[0]
+    else:
+        table = build_row_table(ranks_bev, interval_starts, B, Z * Y * X, X,
+                                counts=counts, attach=False)
+    out = torch.empty((B, C, Z // dz, Y // dy, X // dx), dtype=torch.float32,
+                      device=dev)
+    with torch.cuda.device(dev):
+        st = _lib.lib().veon_bev_pool_v2_fwd_maxpool(
+            C, interval_starts.numel(), B, Z, Y, X, dz, dy, dx, _lib.ptr(depth),
+            _lib.ptr(feat), _lib.ptr(ranks_depth), _lib.ptr(ranks_feat),
+            _lib.ptr(ranks_bev), _lib.ptr(interval_starts),
+            _lib.ptr(interval_lengths), _lib.ptr(table), _lib.ptr(out),
+            _lib.stream_ptr(dev))
+    _lib.check(st, 'veon_bev_pool_v2_fwd_maxpool')
     return out
 
 
