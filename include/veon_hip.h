@@ -191,6 +191,23 @@ int veon_lss_prepare(int B, int N, int D, int H, int W, const float *coor,
                      int *interval_lengths, int *plan, int *counts,
                      void *stream);
 
+/*
+ * Depth preparation (LSSViewTransformerRaw.downsample_depth /
+ * get_two_hot_depth, view_transformer_raw.py:393-429).
+ * veon_downsample_depth: depths (BN,H,W) -> out (BN,H/ds,W/ds), min over the
+ *   non-zero pixels of each block (zeros count as 1e5).
+ * veon_two_hot_depth: out (BN,D,H,W) = softmax over the D+1 bin centres
+ *   c_k = k*step + (lo + step/2) of -gamma*|d - c_k| clamped at -16, last bin
+ *   dropped.  ds == 0: depths is (BN,H,W); ds > 0: depths is (BN,H*ds,W*ds) and
+ *   the block-min is fused in (the two calls of AlignNetOcc3D.prepare_depth,
+ *   align_net_occ3d.py:320-326, in one pass).
+ */
+int veon_downsample_depth(int BN, int H, int W, int ds, const float *depths,
+                          float *out, void *stream);
+int veon_two_hot_depth(int BN, int H, int W, int ds, int D, float lo, float step,
+                       float gamma, const float *depths, float *out,
+                       void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -338,3 +338,27 @@ def test_fused_maxpool_general_factors_and_negative_blocks():
                                      dev(rb), shape, dev(st), dev(ln), ds)
         assert np.array_equal(got.cpu().numpy(), want), ds
     assert (full[0, :, 0, 0, :5] < 0).all()   # the all-negative block exists
+
+
+# ------------------------------------------------------------------ depth prep
+@pytest.mark.parametrize('name', ['lss_small', 'lss_small_b2', 'lss_mid'])
+def test_hip_depth_prep(name):
+    from veon_amd import depth_ops
+    g = load_golden(name)
+    vt = _raw_from_golden(g)
+    md = dev(g['metric_depth'])
+    ds = vt.downsample_depth(md, 8)
+    assert np.array_equal(ds.cpu().numpy(), g['ds_depth'])        # exact (min)
+    th = vt.get_two_hot_depth(ds)
+    assert th.shape == g['two_hot'].shape and th.is_contiguous()
+    # expf vs torch's vectorised exp: stated fp32 tolerance
+    np.testing.assert_allclose(th.cpu().numpy(), g['two_hot'], rtol=1e-5, atol=1e-8)
+    lo, _, step = g['grid_depth']
+    fused = depth_ops.two_hot_depth_fused(md, 8, vt.D, lo, step, 4)
+    assert torch.equal(fused, th)
+    # bit-exact against the C oracle built on the same libm-free formula? no:
+    # expf implementations differ; compare with the same tolerance
+    want = c_oracle.two_hot_depth(g['ds_depth'], vt.D, lo, step, 4.0)
+    np.testing.assert_allclose(th.cpu().numpy(), want, rtol=1e-5, atol=1e-8)
+    # sums to < 1 (last bin dropped) and the two largest bins straddle d
+    assert (th.sum(2) <= 1.0 + 1e-5).all()

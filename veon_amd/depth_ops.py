@@ -40,3 +40,16 @@ def two_hot_depth(depths, D, lo, step, gamma=4):
     if depths.is_cuda and _HIP is not None:
         return _HIP.two_hot_depth(depths, D, lo, step, gamma)
     return two_hot_depth_torch(depths, D, lo, step, gamma)
+
+
+def two_hot_depth_fused(depths, downsample, D, lo, step, gamma=4):
+    """downsample_depth + get_two_hot_depth in one pass on a ROCm device
+    (AlignNetOcc3D.prepare_depth, align_net_occ3d.py:320-326)."""
+    if depths.is_cuda and _HIP is not None:
+        return _HIP.two_hot_depth(depths, D, lo, step, gamma,
+                                  fused_downsample=downsample)
+    return two_hot_depth_torch(downsample_depth_torch(depths, downsample), D,
+                               lo, step, gamma)
+
+
+from . import depth_ops_hip  # noqa: E402,F401  (registers the device path)

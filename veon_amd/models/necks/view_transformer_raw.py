@@ -51,9 +51,10 @@ class LSSViewTransformerRaw(LSSCore):
         """Metric depth (B,N,H,W) -> soft two-hot distribution (B,N,D,H,W):
         softmax over D+1 bin centres of -gamma*|d - c_k| clamped at -16, last
         bin dropped (:406-429)."""
-        if downsample:
-            depths = self.downsample_depth(depths, self.downsample)
         lo, _, step = self.grid_config['depth']
+        if downsample:
+            return depth_ops.two_hot_depth_fused(depths, self.downsample, self.D,
+                                                 lo, step, gamma)
         return depth_ops.two_hot_depth(depths, self.D, lo, step, gamma)
 
     def get_one_hot_depth(self, depths, downsample=False):
