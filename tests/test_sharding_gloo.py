@@ -1,0 +1,102 @@
+"""N>1 paths on CPU: world_size-2 gloo process groups (no GPU).  The per-rank
+lift is the CPU oracle (tests may use it); what is under test is the camera
+partition, the all-reduce and the max-pool-after-reduce order."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import lss_torch
+from veon_amd import sharding, synthetic
+from veon_amd.models import build_neck
+
+GRID = {'x': [-40, 40, 4.0], 'y': [-40, 40, 4.0], 'z': [-1, 5.4, 1.6],
+        'depth': [1.0, 33.0, 4.0]}
+SIZE = (64, 176)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _oracle_lift(vt, input, depth):
+    """Un-pooled (B,C,Z,Y,X) volume of the given cameras on CPU."""
+    grid = (vt.grid_lower_bound, vt.grid_interval, vt.grid_size)
+    cams = (input[1], input[3], input[4], input[5], input[6])
+    return lss_torch.lift(vt.frustum, grid, cams, depth, input[0])
+
+
+def _make_case(n_cams=6, C=8, batch=2):
+    rig = synthetic.make_rig(batch, n_cams, SIZE)
+    vt = build_neck(dict(type='LSSViewTransformerRaw', grid_config=GRID,
+                         input_size=SIZE, out_channels=C, collapse_z=False,
+                         ds_feat=[2, 2, 2]))
+    depth, feat = synthetic.make_depth_feat(batch, n_cams, vt.D, C, 4, 11, seed=5)
+    return vt, [feat] + list(synthetic.rig_inputs(rig)), depth
+
+
+def _worker(rank, world, port, n_cams, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(1)
+        vt, inp, depth = _make_case(n_cams)
+        sharded = sharding.CameraShardedLift(vt, lift_fn=_oracle_lift)
+        out = sharded(inp, depth)
+        full = lss_torch.maxpool(_oracle_lift(vt, inp, depth), (2, 2, 2))
+        # every rank holds the same reduced volume
+        gathered = [torch.empty_like(out) for _ in range(world)]
+        dist.all_gather(gathered, out)
+        same = all(torch.equal(g, out) for g in gathered)
+        err = (out - full).abs().max().item()
+        q.put((rank, tuple(out.shape), same, err, float(full.abs().max())))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world,n_cams', [(2, 6), (2, 1), (3, 2)])
+def test_camera_sharded_lift_matches_full(world, n_cams):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_cams, q))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, shape, same, err, scale in res:
+        assert shape == (2, 8, 2, 10, 10)
+        assert same
+        # all-reduce changes the summation order: fp32 tolerance, not bitwise
+        assert err <= 1e-5 * max(scale, 1.0), (rank, err, scale)
+
+
+def test_slices_partition_everything():
+    for n in (1, 2, 6, 7, 13):
+        for w in (1, 2, 3, 4, 8):
+            sl = sharding.camera_slices(n, w)
+            assert sl[0][0] == 0 and sl[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(sl, sl[1:]))
+            sizes = [b - a for a, b in sl]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_slice_cameras_keeps_per_sample_tensors():
+    vt, inp, depth = _make_case()
+    li, ld = sharding.slice_cameras(inp, depth, 2, 5)
+    assert li[0].shape[1] == 3 and ld.shape[1] == 3
+    assert li[1].shape[:2] == (2, 3) and li[5].shape[:2] == (2, 3)
+    assert li[6].shape == (2, 3, 3)          # bda is per sample
+    assert torch.equal(li[3], inp[3][:, 2:5])
