@@ -208,6 +208,39 @@ int veon_two_hot_depth(int BN, int H, int W, int ds, int D, float lo, float step
                        float gamma, const float *depths, float *out,
                        void *stream);
 
+/*
+ * ViT encoder block kernels (bf16 operands on MFMA, fp32 accumulate, fp32
+ * residual stream): the dense contractions of the DINOv2 blocks of
+ * DepthAnythingV2 (mmdet3d/models/depth_anything/dinov2_layers/block.py:85-110,
+ * attention.py:56-69, mlp.py:40-46, layer_scale.py:27) and of the CLIP
+ * residual-attention blocks (semantic_net/clip_utils/visual.py:57-91,
+ * attn_helper.py:303-314).  bf16 buffers are passed as void* (uint16 storage).
+ *
+ * veon_vit_cast_bf16 : fp32 -> bf16 (round to nearest even), n elements.
+ * veon_vit_layernorm : x fp32 [T,d] -> bf16 [T,d]; nn.LayerNorm semantics
+ *                      (biased variance, eps inside the sqrt), d <= 2048.
+ * veon_vit_gemm      : C[M,N] = A[M,K] . W[N,K]^T (+ bias[N]); W is the
+ *                      nn.Linear weight layout.  K % 64 == 0, N % 4 == 0.
+ *                      epilogue 0: -> bf16 out;  1: GELU(erf) -> bf16 out;
+ *                      2: QuickGELU x*sigmoid(1.702x) -> bf16 out;
+ *                      3: resid[M,N] (fp32, in place) += gamma[N] * C
+ *                         (gamma NULL = 1): LayerScale + residual add.
+ * veon_vit_attention : qkv bf16 [B,T,3,H,64] (q pre-scaled) -> out bf16
+ *                      [B,T,H*64] = softmax(q k^T + bias) v, flash style.
+ *                      bias (optional) fp32 [.,.,T,T] with batch / head strides
+ *                      in elements (0 = broadcast).  head_dim must be 64.
+ */
+int veon_vit_cast_bf16(const float *in, void *out_bf16, int64_t n, void *stream);
+int veon_vit_layernorm(const float *x, const float *gamma, const float *beta,
+                       void *out_bf16, int T, int d, float eps, void *stream);
+int veon_vit_gemm(const void *a_bf16, const void *w_bf16, const float *bias,
+                  const float *gamma, float *resid, void *out_bf16, int M, int N,
+                  int K, int epilogue, void *stream);
+int veon_vit_attention(const void *qkv_bf16, const float *bias,
+                       int64_t bias_batch_stride, int64_t bias_head_stride,
+                       void *out_bf16, int B, int T, int H, int head_dim,
+                       void *stream);
+
 #ifdef __cplusplus
 }
 #endif

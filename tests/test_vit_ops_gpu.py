@@ -1,0 +1,113 @@
+"""ViT block kernels (bf16 MFMA) against plain PyTorch fp32 references of the
+same ops on the same (bf16-rounded) operands.  Tolerances are stated per test:
+the products are exact in fp32 accumulation, so the error budget is the bf16
+rounding of the OUTPUT (2^-9 relative) plus accumulation-order noise."""
+import numpy as np
+import pytest
+import torch
+
+from veon_amd import vit_ops
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(DEV)
+
+
+def test_cast_bf16_round_to_nearest_even():
+    x = _rand(1000, 37, seed=1)
+    got = vit_ops.to_bf16(x)
+    assert torch.equal(got, x.to(torch.bfloat16))
+
+
+@pytest.mark.parametrize('T,d', [(901, 768), (17, 1024), (5, 384), (3, 100)])
+def test_layernorm(T, d):
+    x = _rand(T, d, seed=2, scale=3.0) + 0.5
+    w = _rand(d, seed=3) * 0.1 + 1.0
+    b = _rand(d, seed=4) * 0.1
+    got = vit_ops.layernorm(x, w, b, eps=1e-6).float()
+    ref = torch.nn.functional.layer_norm(x, (d,), w, b, 1e-6)
+    # output is bf16: half-ulp relative error 2^-9, plus fp32 reduction noise
+    torch.testing.assert_close(got, ref, rtol=2 ** -8, atol=2e-3)
+
+
+@pytest.mark.parametrize('M,N,K', [(901, 768, 768), (5406, 2304, 768),
+                                   (130, 3072, 768), (64, 128, 64), (1, 4, 64),
+                                   (300, 1024, 4096)])
+def test_gemm_bias_bf16(M, N, K):
+    a = _rand(M, K, seed=5).to(torch.bfloat16)
+    w = (_rand(N, K, seed=6) * K ** -0.5).to(torch.bfloat16)
+    bias = _rand(N, seed=7)
+    got = vit_ops.linear(a, w, bias).float()
+    ref = a.float() @ w.float().t() + bias
+    torch.testing.assert_close(got, ref, rtol=2 ** -8, atol=2e-3)
+    got_nb = vit_ops.linear(a, w, None).float()
+    torch.testing.assert_close(got_nb, a.float() @ w.float().t(),
+                               rtol=2 ** -8, atol=2e-3)
+
+
+def test_gemm_gelu_and_quickgelu():
+    M, N, K = 901, 3072, 768
+    a = _rand(M, K, seed=8).to(torch.bfloat16)
+    w = (_rand(N, K, seed=9) * K ** -0.5).to(torch.bfloat16)
+    bias = _rand(N, seed=10)
+    pre = a.float() @ w.float().t() + bias
+    got = vit_ops.linear(a, w, bias, vit_ops.EPI_GELU).float()
+    torch.testing.assert_close(got, torch.nn.functional.gelu(pre),
+                               rtol=2 ** -8, atol=2e-3)
+    got = vit_ops.linear(a, w, bias, vit_ops.EPI_QUICKGELU).float()
+    torch.testing.assert_close(got, pre * torch.sigmoid(1.702 * pre),
+                               rtol=2 ** -8, atol=2e-3)
+
+
+def test_gemm_layerscale_residual_inplace():
+    M, N, K = 901, 768, 3072
+    a = _rand(M, K, seed=11).to(torch.bfloat16)
+    w = (_rand(N, K, seed=12) * K ** -0.5).to(torch.bfloat16)
+    bias = _rand(N, seed=13)
+    gamma = _rand(N, seed=14) * 0.1
+    x = _rand(M, N, seed=15)
+    ref = x + gamma * (a.float() @ w.float().t() + bias)
+    got = vit_ops.linear_residual_(x.clone(), a, w, bias, gamma)
+    # fp32 output: only accumulation-order noise
+    torch.testing.assert_close(got, ref, rtol=1e-4, atol=1e-4)
+    got2 = vit_ops.linear_residual_(x.clone(), a, w, None, None)
+    torch.testing.assert_close(got2, x + a.float() @ w.float().t(),
+                               rtol=1e-4, atol=1e-4)
+
+
+def _ref_attention(qkv, H, bias=None):
+    B, T, _ = qkv.shape
+    q, k, v = qkv.float().view(B, T, 3, H, 64).permute(2, 0, 3, 1, 4)
+    s = q @ k.transpose(-1, -2)
+    if bias is not None:
+        s = s + bias
+    return (s.softmax(-1) @ v).transpose(1, 2).reshape(B, T, H * 64)
+
+
+@pytest.mark.parametrize('B,T,H', [(2, 901, 12), (1, 64, 1), (1, 65, 2),
+                                   (3, 17, 3), (1, 705, 12), (1, 300, 16)])
+def test_attention(B, T, H):
+    qkv = (_rand(B, T, 3 * H * 64, seed=16) * 0.5).to(torch.bfloat16)
+    got = vit_ops.attention(qkv, H).float()
+    ref = _ref_attention(qkv, H)
+    # P is rounded to bf16 before P.V (2^-9 relative on each weight), output bf16
+    torch.testing.assert_close(got, ref, rtol=2 ** -7, atol=4e-3)
+
+
+def test_attention_with_bias_and_masking():
+    B, T, H = 2, 130, 4
+    qkv = (_rand(B, T, 3 * H * 64, seed=17) * 0.5).to(torch.bfloat16)
+    bias = _rand(B, H, T, T, seed=18)
+    bias[:, :, :, 100:] = float('-inf')     # masked keys (attn_mask style)
+    got = vit_ops.attention(qkv, H, bias).float()
+    ref = _ref_attention(qkv, H, bias)
+    torch.testing.assert_close(got, ref, rtol=2 ** -7, atol=4e-3)
+    # head-broadcast bias
+    b1 = bias[:1, :1].contiguous()
+    got = vit_ops.attention(qkv, H, b1).float()
+    torch.testing.assert_close(got, _ref_attention(qkv, H, b1), rtol=2 ** -7,
+                               atol=4e-3)

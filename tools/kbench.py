@@ -182,7 +182,7 @@ def main():
             f()
         return g
     cases.append(('var43 cs=%d' % cs_opts[0], var(43, cs_opts[0])))
-    for v in [43, 81, 86, 87]:
+    for v in [43, 95, 98, 99]:
         for cs in cs_opts:
             cases.append(('var%d cs=%d' % (v, cs), var(v, cs)))
     for v in []:

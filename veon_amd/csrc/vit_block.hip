@@ -1,0 +1,490 @@
+// ViT encoder block kernels for MI355X (gfx950 / CDNA4): bf16 operands on the
+// matrix cores (v_mfma_f32_16x16x32_bf16), fp32 accumulation, fp32 residual
+// stream.  These are the dense contractions of the image encoders that front
+// the lift: DINOv2 blocks of DepthAnythingV2
+// (mmdet3d/models/depth_anything/dinov2_layers/block.py:85-110,
+//  attention.py:56-69, mlp.py:40-46, layer_scale.py) and the CLIP residual
+// attention blocks (semantic_net/clip_utils/visual.py, attn_helper.py).
+//
+//   k_layernorm      x fp32 [T,d] -> bf16 [T,d]                  (HBM-bound)
+//   k_gemm_bf16      C[M,N] = A[M,K] . W[N,K]^T  (+bias, and one of: ->bf16,
+//                    GELU->bf16, QuickGELU->bf16, *gamma + residual -> fp32)
+//   k_attention      softmax(q k^T [+ bias]) v, flash style, head_dim 64
+//
+// Fragment convention (guide section 3): for mfma_f32_16x16x32_bf16 lane l
+// holds A[row l&15][k = 8(l>>4)+j] and B[k = 8(l>>4)+j][col l&15], j = 0..7;
+// D[row 4(l>>4)+reg][col l&15].  Both GEMM operands are K-contiguous rows, so
+// both fragments are 16-byte LDS reads.  The kernels feed the WEIGHT (or K, or
+// V^T) as the MFMA "A" operand and the ACTIVATION (or Q, or P) as "B": the
+// accumulator then holds 4 consecutive output features of ONE token per lane
+// (16-byte epilogue accesses, per-token softmax statistics stay lane-local).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/veon_hip.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(4))) short bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef unsigned short bf16_t;
+
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  // round to nearest even; NaN stays NaN
+  unsigned u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ float bf2f(bf16_t h) {
+  return __uint_as_float(((unsigned)h) << 16);
+}
+
+inline int launch_status() {
+  return hipGetLastError() == hipSuccess ? VEON_OK : VEON_ERR_LAUNCH;
+}
+
+// ------------------------------------------------------------------ LayerNorm
+// one wave per token row; d <= 64 * kMaxPerLane
+constexpr int kLnMaxPerLane = 32;
+
+__global__ __launch_bounds__(256) void k_layernorm(
+    const float* __restrict__ x, const float* __restrict__ gamma,
+    const float* __restrict__ beta, bf16_t* __restrict__ out, int T, int d,
+    float eps) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= T) return;
+  const float* xr = x + (int64_t)row * d;
+  float v[kLnMaxPerLane];
+  float s = 0.f;
+  const int n = (d + 63) / 64;
+#pragma unroll
+  for (int i = 0; i < kLnMaxPerLane; ++i) {
+    if (i < n) {
+      const int c = i * 64 + lane;
+      v[i] = c < d ? xr[c] : 0.f;
+      s += v[i];
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+  const float mean = s / (float)d;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < kLnMaxPerLane; ++i) {
+    if (i < n) {
+      const int c = i * 64 + lane;
+      const float t = c < d ? v[i] - mean : 0.f;
+      q += t * t;
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) q += __shfl_xor(q, off);
+  const float rstd = rsqrtf(q / (float)d + eps);
+  bf16_t* o = out + (int64_t)row * d;
+#pragma unroll
+  for (int i = 0; i < kLnMaxPerLane; ++i) {
+    if (i < n) {
+      const int c = i * 64 + lane;
+      if (c < d) o[c] = f2bf((v[i] - mean) * rstd * gamma[c] + beta[c]);
+    }
+  }
+}
+
+// ----------------------------------------------------------------------- GEMM
+// 128x128 output tile, BK = 64, 256 threads = 4 waves in 2(M) x 2(N), each wave
+// 64 tokens x 64 features = 4x4 MFMA tiles.  Operands staged global -> regs ->
+// LDS (rows padded to 72 bf16 = 144 B: conflict-free 16-B fragment reads),
+// double-buffered so the next K-slab's loads fly under the MFMAs.
+constexpr int BM = 128, BN = 128, BK = 64, LDK = BK + 8;
+
+enum { EPI_BF16 = 0, EPI_GELU = 1, EPI_QUICKGELU = 2, EPI_RESID = 3 };
+
+__device__ __forceinline__ float gelu_erf(float x) {
+  return 0.5f * x * (1.f + erff(x * 0.70710678118654752f));
+}
+__device__ __forceinline__ float quick_gelu(float x) {
+  return x / (1.f + __expf(-1.702f * x));
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256) void k_gemm_bf16(
+    const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
+    const float* __restrict__ bias, const float* __restrict__ gamma,
+    float* __restrict__ resid, bf16_t* __restrict__ out, int M, int N, int K) {
+  __shared__ __attribute__((aligned(16))) bf16_t sA[2][BM * LDK];
+  __shared__ __attribute__((aligned(16))) bf16_t sW[2][BN * LDK];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int fr = lane & 15, fg = lane >> 4;
+
+  // staging map: 128 rows x 64 k = 1024 chunks of 8 bf16; 4 per thread
+  bf16x8 ra[4], rw[4];
+  auto load_tiles = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int ch = tid + i * 256;
+      const int r = ch >> 3, kc = (ch & 7) * 8;
+      const int gm = m0 + r;
+      if (gm < M)
+        ra[i] = *reinterpret_cast<const bf16x8*>(A + (int64_t)gm * K + k0 + kc);
+      else
+        ra[i] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      const int gn = n0 + r;
+      if (gn < N)
+        rw[i] = *reinterpret_cast<const bf16x8*>(W + (int64_t)gn * K + k0 + kc);
+      else
+        rw[i] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
+  };
+  auto store_tiles = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int ch = tid + i * 256;
+      const int r = ch >> 3, kc = (ch & 7) * 8;
+      *reinterpret_cast<bf16x8*>(&sA[buf][r * LDK + kc]) = ra[i];
+      *reinterpret_cast<bf16x8*>(&sW[buf][r * LDK + kc]) = rw[i];
+    }
+  };
+
+  f32x4 acc[4][4];  // [token tile][feature tile]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  load_tiles(0);
+  store_tiles(0);
+  __syncthreads();
+  const int nk = K / BK;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) load_tiles((kt + 1) * BK);
+#pragma unroll
+    for (int ks = 0; ks < BK / 32; ++ks) {
+      bf16x8 fa[4], fw[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        fa[i] = *reinterpret_cast<const bf16x8*>(
+            &sA[buf][(wm * 64 + i * 16 + fr) * LDK + ks * 32 + fg * 8]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        fw[j] = *reinterpret_cast<const bf16x8*>(
+            &sW[buf][(wn * 64 + j * 16 + fr) * LDK + ks * 32 + fg * 8]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          // weight rows as MFMA "A", token rows as "B":
+          // acc[i][j][reg] = C[token i*16 + fr][feature j*16 + 4*fg + reg]
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i],
+                                                               acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) store_tiles(buf ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue: lane owns 4 consecutive features of one token per tile
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + wm * 64 + i * 16 + fr;
+    if (m >= M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wn * 64 + j * 16 + fg * 4;
+      if (n >= N) continue;
+      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      if (bias != nullptr) {
+        const float4 b4 = *reinterpret_cast<const float4*>(bias + n);
+        v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+      }
+      if (EPI == EPI_RESID) {
+        float* rp = resid + (int64_t)m * N + n;
+        float4 r4 = *reinterpret_cast<const float4*>(rp);
+        if (gamma != nullptr) {
+          const float4 g4 = *reinterpret_cast<const float4*>(gamma + n);
+          v[0] *= g4.x; v[1] *= g4.y; v[2] *= g4.z; v[3] *= g4.w;
+        }
+        r4.x += v[0]; r4.y += v[1]; r4.z += v[2]; r4.w += v[3];
+        *reinterpret_cast<float4*>(rp) = r4;
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          if (EPI == EPI_GELU) v[k] = gelu_erf(v[k]);
+          if (EPI == EPI_QUICKGELU) v[k] = quick_gelu(v[k]);
+        }
+        bf16x4 o;
+        o[0] = (short)f2bf(v[0]); o[1] = (short)f2bf(v[1]);
+        o[2] = (short)f2bf(v[2]); o[3] = (short)f2bf(v[3]);
+        *reinterpret_cast<bf16x4*>(out + (int64_t)m * N + n) = o;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------ attention
+// qkv: [B, T, 3, H, 64] bf16 (the packed output of the qkv projection, q already
+// scaled by head_dim^-0.5 through the weights).  out: [B, T, H*64] bf16.
+// Optional additive bias [B or 1][H or 1][T][T] fp32 (CLIP tail; strides given).
+// Workgroup = 256 threads = 4 waves, 64 queries per wave; keys/values streamed
+// in tiles of 64 through LDS (K row-major, V transposed).
+constexpr int HD = 64;        // head dim
+constexpr int AQ = 64;        // queries per wave
+constexpr int AK = 64;        // keys per LDS tile
+constexpr int LDD = HD + 8;   // K tile row pitch (bf16)
+constexpr int LDT = AK + 8;   // V^T tile row pitch (bf16)
+
+__global__ __launch_bounds__(256) void k_attention(
+    const bf16_t* __restrict__ qkv, const float* __restrict__ bias,
+    int64_t bias_sb, int64_t bias_sh, bf16_t* __restrict__ out, int T, int H) {
+  __shared__ __attribute__((aligned(16))) bf16_t sK[AK * LDD];
+  __shared__ __attribute__((aligned(16))) bf16_t sVt[HD * LDT];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int q0 = (blockIdx.x * 4 + wave) * AQ;
+  const int64_t tok_stride = (int64_t)3 * H * HD;
+  const bf16_t* qb = qkv + (int64_t)b * T * tok_stride + (int64_t)h * HD;
+  const bf16_t* kb = qb + (int64_t)H * HD;
+  const bf16_t* vb = qb + (int64_t)2 * H * HD;
+
+  // Q fragments (B operand of S^T = K . Q^T): lane holds Q[q = fr][d = 8fg + j]
+  bf16x8 qf[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int q = q0 + i * 16 + fr;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      if (q < T)
+        qf[i][ks] = *reinterpret_cast<const bf16x8*>(qb + (int64_t)q * tok_stride +
+                                                     ks * 32 + fg * 8);
+      else
+        qf[i][ks] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
+  }
+  f32x4 o[4][4];  // [q tile][d tile]: O^T[d = 4fg + reg][q = fr]
+  float mrow[4], lrow[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    mrow[i] = -INFINITY;
+    lrow[i] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const float* brow = nullptr;
+  if (bias != nullptr) brow = bias + b * bias_sb + h * bias_sh;
+
+  for (int k0 = 0; k0 < T; k0 += AK) {
+    __syncthreads();  // previous tile fully consumed
+    // stage K tile [64 keys][64 d] and V^T tile [64 d][64 keys]
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int ch = tid + i * 256;         // 512 chunks of 8 bf16
+      const int r = ch >> 3, dc = (ch & 7) * 8;
+      const int key = k0 + r;
+      bf16x8 kv = bf16x8{0, 0, 0, 0, 0, 0, 0, 0}, vv = kv;
+      if (key < T) {
+        kv = *reinterpret_cast<const bf16x8*>(kb + (int64_t)key * tok_stride + dc);
+        vv = *reinterpret_cast<const bf16x8*>(vb + (int64_t)key * tok_stride + dc);
+      }
+      *reinterpret_cast<bf16x8*>(&sK[r * LDD + dc]) = kv;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sVt[(dc + e) * LDT + r] = (bf16_t)vv[e];
+    }
+    __syncthreads();
+
+    // S^T tiles: s[i][kt][reg] = S[q = i*16 + fr][key = kt*16 + 4fg + reg]
+    f32x4 s[4][4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      bf16x8 kf[2];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+        kf[ks] = *reinterpret_cast<const bf16x8*>(
+            &sK[(kt * 16 + fr) * LDD + ks * 32 + fg * 8]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[0], qf[i][0], a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[1], qf[i][1], a, 0, 0, 0);
+        s[i][kt] = a;
+      }
+    }
+    // bias, key mask, online softmax (statistics per q = fr, lane-local after
+    // a 4-group shuffle reduction)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int q = q0 + i * 16 + fr;
+      float mx = -INFINITY;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = k0 + kt * 16 + fg * 4 + r;
+          float v = s[i][kt][r];
+          if (brow != nullptr && q < T && key < T) v += brow[(int64_t)q * T + key];
+          if (key >= T) v = -INFINITY;
+          s[i][kt][r] = v;
+          mx = fmaxf(mx, v);
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 16));
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      const float mnew = fmaxf(mrow[i], mx);
+      const float corr = (mrow[i] == -INFINITY) ? 0.f : __expf(mrow[i] - mnew);
+      float rs = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = (mnew == -INFINITY) ? 0.f : __expf(s[i][kt][r] - mnew);
+          s[i][kt][r] = p;
+          rs += p;
+        }
+      rs += __shfl_xor(rs, 16);
+      rs += __shfl_xor(rs, 32);
+      lrow[i] = lrow[i] * corr + rs;
+      mrow[i] = mnew;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        o[i][j][0] *= corr; o[i][j][1] *= corr;
+        o[i][j][2] *= corr; o[i][j][3] *= corr;
+      }
+    }
+    // O^T += V^T . P^T : MFMA k-slot (8fg + j) <-> key
+    //   j < 4 : key tile 2*kk,   keys 4fg + j
+    //   j >= 4: key tile 2*kk+1, keys 4fg + (j-4)
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 pf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          pf[i][r] = (short)f2bf(s[i][2 * kk][r]);
+          pf[i][4 + r] = (short)f2bf(s[i][2 * kk + 1][r]);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        // V^T fragment: row d = j*16 + fr, the same key permutation
+        const bf16_t* vr = &sVt[(j * 16 + fr) * LDT];
+        const bf16x4 v0 = *reinterpret_cast<const bf16x4*>(vr + (2 * kk) * 16 + fg * 4);
+        const bf16x4 v1 = *reinterpret_cast<const bf16x4*>(vr + (2 * kk + 1) * 16 + fg * 4);
+        bf16x8 vf;
+        vf[0] = v0[0]; vf[1] = v0[1]; vf[2] = v0[2]; vf[3] = v0[3];
+        vf[4] = v1[0]; vf[5] = v1[1]; vf[6] = v1[2]; vf[7] = v1[3];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          o[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[i], o[i][j], 0, 0, 0);
+      }
+    }
+  }
+  // normalise and store: lane owns O[q = fr][d = j*16 + 4fg .. +3]
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int q = q0 + i * 16 + fr;
+    if (q >= T) continue;
+    const float inv = lrow[i] > 0.f ? 1.f / lrow[i] : 0.f;
+    bf16_t* op = out + ((int64_t)b * T + q) * (int64_t)H * HD + (int64_t)h * HD;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      bf16x4 w4;
+      w4[0] = (short)f2bf(o[i][j][0] * inv);
+      w4[1] = (short)f2bf(o[i][j][1] * inv);
+      w4[2] = (short)f2bf(o[i][j][2] * inv);
+      w4[3] = (short)f2bf(o[i][j][3] * inv);
+      *reinterpret_cast<bf16x4*>(op + j * 16 + fg * 4) = w4;
+    }
+  }
+}
+
+// fp32 -> bf16 cast (weights / activations entering the bf16 path)
+__global__ __launch_bounds__(256) void k_cast_bf16(const float* __restrict__ in,
+                                                   bf16_t* __restrict__ out,
+                                                   int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = f2bf(in[i]);
+}
+
+inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+}  // namespace
+
+extern "C" {
+
+int veon_vit_cast_bf16(const float* in, void* out, int64_t n, void* stream) {
+  if (n < 0 || (n > 0 && (!in || !out))) return VEON_ERR_BAD_ARG;
+  if (n == 0) return VEON_OK;
+  hipLaunchKernelGGL(k_cast_bf16, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), in,
+                     static_cast<bf16_t*>(out), n);
+  return launch_status();
+}
+
+int veon_vit_layernorm(const float* x, const float* gamma, const float* beta,
+                       void* out_bf16, int T, int d, float eps, void* stream) {
+  if (T <= 0 || d <= 0 || d > 64 * kLnMaxPerLane || !x || !gamma || !beta ||
+      !out_bf16)
+    return VEON_ERR_BAD_ARG;
+  hipLaunchKernelGGL(k_layernorm, dim3((unsigned)((T + 3) / 4)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), x, gamma, beta,
+                     static_cast<bf16_t*>(out_bf16), T, d, eps);
+  return launch_status();
+}
+
+int veon_vit_gemm(const void* a_bf16, const void* w_bf16, const float* bias,
+                  const float* gamma, float* resid, void* out_bf16, int M, int N,
+                  int K, int epilogue, void* stream) {
+  if (M <= 0 || N <= 0 || K <= 0 || K % BK != 0 || N % 4 != 0 || !a_bf16 ||
+      !w_bf16)
+    return VEON_ERR_BAD_ARG;
+  if (epilogue == EPI_RESID ? !resid : !out_bf16) return VEON_ERR_BAD_ARG;
+  if (!al16(a_bf16) || !al16(w_bf16) || (bias && !al16(bias)) ||
+      (gamma && !al16(gamma)) || (resid && !al16(resid)))
+    return VEON_ERR_BAD_ARG;
+  const dim3 grid((unsigned)((N + BN - 1) / BN), (unsigned)((M + BM - 1) / BM));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const bf16_t* A = static_cast<const bf16_t*>(a_bf16);
+  const bf16_t* W = static_cast<const bf16_t*>(w_bf16);
+  bf16_t* O = static_cast<bf16_t*>(out_bf16);
+  switch (epilogue) {
+    case EPI_BF16:
+      hipLaunchKernelGGL(k_gemm_bf16<EPI_BF16>, grid, dim3(256), 0, s, A, W, bias,
+                         gamma, resid, O, M, N, K);
+      break;
+    case EPI_GELU:
+      hipLaunchKernelGGL(k_gemm_bf16<EPI_GELU>, grid, dim3(256), 0, s, A, W, bias,
+                         gamma, resid, O, M, N, K);
+      break;
+    case EPI_QUICKGELU:
+      hipLaunchKernelGGL(k_gemm_bf16<EPI_QUICKGELU>, grid, dim3(256), 0, s, A, W,
+                         bias, gamma, resid, O, M, N, K);
+      break;
+    case EPI_RESID:
+      hipLaunchKernelGGL(k_gemm_bf16<EPI_RESID>, grid, dim3(256), 0, s, A, W, bias,
+                         gamma, resid, O, M, N, K);
+      break;
+    default:
+      return VEON_ERR_BAD_ARG;
+  }
+  return launch_status();
+}
+
+int veon_vit_attention(const void* qkv_bf16, const float* bias,
+                       int64_t bias_batch_stride, int64_t bias_head_stride,
+                       void* out_bf16, int B, int T, int H, int head_dim,
+                       void* stream) {
+  if (B <= 0 || T <= 0 || H <= 0 || head_dim != HD || !qkv_bf16 || !out_bf16)
+    return VEON_ERR_BAD_ARG;
+  if (!al16(qkv_bf16) || !al16(out_bf16)) return VEON_ERR_BAD_ARG;
+  const dim3 grid((unsigned)((T + 4 * AQ - 1) / (4 * AQ)), (unsigned)H, (unsigned)B);
+  hipLaunchKernelGGL(k_attention, grid, dim3(256), 0,
+                     static_cast<hipStream_t>(stream),
+                     static_cast<const bf16_t*>(qkv_bf16), bias,
+                     bias_batch_stride, bias_head_stride,
+                     static_cast<bf16_t*>(out_bf16), T, H);
+  return launch_status();
+}
+
+}  // extern "C"
