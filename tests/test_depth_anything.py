@@ -1,0 +1,106 @@
+"""DepthAnythingV2 / DINOv2 mirror against golden vectors produced by the
+reference's own Python (oracle/tools/gen_golden_vit.py).
+
+* CPU (fp32 torch path): must reproduce the reference to fp32 rounding.
+* GPU (MFMA bf16 path): stated bf16 tolerance.
+"""
+import numpy as np
+import pytest
+import torch
+
+from tests.conftest import load_golden
+from veon_amd.models.depth_anything import dinov2, dpt
+
+
+def _build(g):
+    d, depth, heads, lora_r = (int(v) for v in g['cfg'])
+    enc = dinov2.DinoVisionTransformer(
+        img_size=70, patch_size=14, embed_dim=d, depth=depth, num_heads=heads,
+        mlp_ratio=4, init_values=1.0, lora_r=lora_r)
+    head = dpt.DPTHead(d, features=8, use_bn=False, out_channels=[4, 8, 16, 16])
+    enc_sd = {k[4:]: torch.from_numpy(v) for k, v in g.items() if k.startswith('enc.')}
+    head_sd = {k[5:]: torch.from_numpy(v) for k, v in g.items() if k.startswith('head.')}
+    missing, unexpected = enc.load_state_dict(enc_sd, strict=True), None
+    head.load_state_dict(head_sd, strict=True)
+    return enc.eval(), head.eval()
+
+
+def test_state_dict_names_match_reference():
+    g = load_golden('dinov2_tiny')
+    enc, head = _build(g)          # strict load = identical key set
+    assert any(k.endswith('attn.qkv.lora_A') for k in enc.state_dict())
+    assert enc.blocks[0].attn.qkv.merged          # eval() merged the LoRA update
+
+
+def test_cpu_path_reproduces_reference():
+    g = load_golden('dinov2_tiny')
+    enc, head = _build(g)
+    x = torch.from_numpy(g['x'])
+    with torch.no_grad():
+        feats = enc.get_intermediate_layers(x, [int(t) for t in g['taps']],
+                                            return_class_token=True)
+        final = enc.forward_features(x)
+        depth = head(feats, 2, 3) * 80.0
+    for i, (p, c) in enumerate(feats):
+        np.testing.assert_allclose(p.numpy(), g['tap_patch'][i], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(c.numpy(), g['tap_cls'][i], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(final['x_prenorm'].numpy(), g['x_prenorm'],
+                               rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(depth.squeeze(1).numpy(), g['depth'], rtol=1e-4,
+                               atol=1e-4)
+
+
+def test_train_mode_unmerges_lora():
+    g = load_golden('dinov2_tiny')
+    enc, _ = _build(g)
+    x = torch.from_numpy(g['x'])
+    with torch.no_grad():
+        a = enc.forward_features(x)['x_prenorm']
+        enc.train()
+        assert not enc.blocks[0].attn.qkv.merged
+        b = enc.forward_features(x)['x_prenorm']
+    torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_gpu_mfma_path_within_bf16_tolerance():
+    g = load_golden('dinov2_tiny')
+    enc, head = _build(g)
+    enc, head = enc.to('cuda:0'), head.to('cuda:0')
+    x = torch.from_numpy(g['x']).to('cuda:0')
+    with torch.no_grad():
+        assert enc._use_hip(x)
+        feats = enc.get_intermediate_layers(x, [int(t) for t in g['taps']],
+                                            return_class_token=True)
+        final = enc.forward_features(x)
+        depth = head(feats, 2, 3) * 80.0
+        enc.use_hip = False
+        ref_final = enc.forward_features(x)['x_prenorm']
+    # bf16 operands (8-bit mantissa), fp32 accumulation and residual stream:
+    # relative L2 error of the features <= 1e-2 after 4 blocks, depth map (after
+    # the fp32 DPT head, sigmoid * 80 m) within 0.25 m
+    def rel(a, b):
+        a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+        return np.linalg.norm(a - b) / np.linalg.norm(b)
+    assert rel(final['x_prenorm'].cpu().numpy(), g['x_prenorm']) < 1e-2
+    assert rel(final['x_prenorm'].cpu().numpy(), ref_final.cpu().numpy()) < 1e-2
+    for i, (p, c) in enumerate(feats):
+        assert rel(p.cpu().numpy(), g['tap_patch'][i]) < 1e-2
+    assert np.abs(depth.squeeze(1).cpu().numpy() - g['depth']).max() < 0.25
+
+
+@pytest.mark.gpu
+def test_gpu_vitb_shape_mfma_vs_torch_fp32():
+    """ViT-B geometry at the real token count (252x700 -> 18x50+1 = 901 tokens,
+    2 images, 3 blocks): MFMA path vs the fp32 torch path on the same weights."""
+    torch.manual_seed(0)
+    enc = dinov2.DinoVisionTransformer(
+        img_size=518, patch_size=14, embed_dim=768, depth=3, num_heads=12,
+        mlp_ratio=4, init_values=1.0, lora_r=16).to('cuda:0').eval()
+    x = torch.randn(2, 3, 252, 700, device='cuda:0')
+    with torch.no_grad():
+        a = enc.forward_features(x)['x_prenorm']
+        enc.use_hip = False
+        b = enc.forward_features(x)['x_prenorm']
+    rel = (a - b).norm() / b.norm()
+    assert a.shape == (2, 901, 768) and rel < 1e-2, rel.item()
