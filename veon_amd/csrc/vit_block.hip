@@ -227,19 +227,24 @@ __global__ __launch_bounds__(256) void k_gemm_bf16(
 // qkv: [B, T, 3, H, 64] bf16 (the packed output of the qkv projection, q already
 // scaled by head_dim^-0.5 through the weights).  out: [B, T, H*64] bf16.
 // Optional additive bias [B or 1][H or 1][T][T] fp32 (CLIP tail; strides given).
-// Workgroup = 256 threads = 4 waves, 64 queries per wave; keys/values streamed
-// in tiles of 64 through LDS (K row-major, V transposed).
+// Workgroup = 256 threads = 4 waves, 32 queries per wave; keys/values streamed
+// in tiles of 64 through LDS, both row-major: K fragments are 16-B row reads,
+// V^T fragments come from the hardware transposing read ds_read_b64_tr_b16.
+// The next tile's global loads are in flight while the current one is consumed.
 constexpr int HD = 64;        // head dim
-constexpr int AQ = 64;        // queries per wave
+constexpr int QT = 2;         // 16-query tiles per wave
+constexpr int AQ = 16 * QT;   // queries per wave
 constexpr int AK = 64;        // keys per LDS tile
-constexpr int LDD = HD + 8;   // K tile row pitch (bf16)
-constexpr int LDT = AK + 8;   // V^T tile row pitch (bf16)
+constexpr int LDD = HD + 8;   // LDS row pitch (bf16): 144 B
+
+typedef short __attribute__((address_space(3))) lds_short;
+typedef bf16x4 __attribute__((address_space(3))) lds_bf16x4;
 
 __global__ __launch_bounds__(256) void k_attention(
     const bf16_t* __restrict__ qkv, const float* __restrict__ bias,
     int64_t bias_sb, int64_t bias_sh, bf16_t* __restrict__ out, int T, int H) {
   __shared__ __attribute__((aligned(16))) bf16_t sK[AK * LDD];
-  __shared__ __attribute__((aligned(16))) bf16_t sVt[HD * LDT];
+  __shared__ __attribute__((aligned(16))) bf16_t sV[AK * LDD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fg = lane >> 4;
   const int b = blockIdx.z, h = blockIdx.y;
@@ -248,11 +253,12 @@ __global__ __launch_bounds__(256) void k_attention(
   const bf16_t* qb = qkv + (int64_t)b * T * tok_stride + (int64_t)h * HD;
   const bf16_t* kb = qb + (int64_t)H * HD;
   const bf16_t* vb = qb + (int64_t)2 * H * HD;
+  constexpr float kLog2e = 1.4426950408889634f;
 
   // Q fragments (B operand of S^T = K . Q^T): lane holds Q[q = fr][d = 8fg + j]
-  bf16x8 qf[4][2];
+  bf16x8 qf[QT][2];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < QT; ++i) {
     const int q = q0 + i * 16 + fr;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -263,10 +269,10 @@ __global__ __launch_bounds__(256) void k_attention(
         qf[i][ks] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
     }
   }
-  f32x4 o[4][4];  // [q tile][d tile]: O^T[d = 4fg + reg][q = fr]
-  float mrow[4], lrow[4];
+  f32x4 o[QT][4];  // [q tile][d tile]: O^T[d = 4fg + reg][q = fr]
+  float mrow[QT], lrow[QT];  // running max (log2 domain) and sum per q = fr
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < QT; ++i) {
     mrow[i] = -INFINITY;
     lrow[i] = 0.f;
 #pragma unroll
@@ -275,27 +281,42 @@ __global__ __launch_bounds__(256) void k_attention(
   const float* brow = nullptr;
   if (bias != nullptr) brow = bias + b * bias_sb + h * bias_sh;
 
-  for (int k0 = 0; k0 < T; k0 += AK) {
-    __syncthreads();  // previous tile fully consumed
-    // stage K tile [64 keys][64 d] and V^T tile [64 d][64 keys]
+  // staging map: 64 rows x 64 d = 512 chunks of 8 bf16 per operand, 2 per thread
+  bf16x8 rk[2], rv[2];
+  auto load_tile = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int ch = tid + i * 256;         // 512 chunks of 8 bf16
+      const int ch = tid + i * 256;
       const int r = ch >> 3, dc = (ch & 7) * 8;
       const int key = k0 + r;
-      bf16x8 kv = bf16x8{0, 0, 0, 0, 0, 0, 0, 0}, vv = kv;
       if (key < T) {
-        kv = *reinterpret_cast<const bf16x8*>(kb + (int64_t)key * tok_stride + dc);
-        vv = *reinterpret_cast<const bf16x8*>(vb + (int64_t)key * tok_stride + dc);
+        rk[i] = *reinterpret_cast<const bf16x8*>(kb + (int64_t)key * tok_stride + dc);
+        rv[i] = *reinterpret_cast<const bf16x8*>(vb + (int64_t)key * tok_stride + dc);
+      } else {
+        rk[i] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        rv[i] = rk[i];
       }
-      *reinterpret_cast<bf16x8*>(&sK[r * LDD + dc]) = kv;
+    }
+  };
+  load_tile(0);
+  // per-lane element offset of the transposing V read: lane 4q+p of a 16-lane
+  // group addresses row q, columns 4p..4p+3 of a 4 x 16 block (guide T10)
+  const int tr_off = (4 * fg + (fr >> 2)) * LDD + 4 * (fr & 3);
+
+  for (int k0 = 0; k0 < T; k0 += AK) {
+    __syncthreads();  // previous tile fully consumed
 #pragma unroll
-      for (int e = 0; e < 8; ++e) sVt[(dc + e) * LDT + r] = (bf16_t)vv[e];
+    for (int i = 0; i < 2; ++i) {
+      const int ch = tid + i * 256;
+      const int r = ch >> 3, dc = (ch & 7) * 8;
+      *reinterpret_cast<bf16x8*>(&sK[r * LDD + dc]) = rk[i];
+      *reinterpret_cast<bf16x8*>(&sV[r * LDD + dc]) = rv[i];
     }
     __syncthreads();
+    if (k0 + AK < T) load_tile(k0 + AK);  // flies under the MFMAs below
 
     // S^T tiles: s[i][kt][reg] = S[q = i*16 + fr][key = kt*16 + 4fg + reg]
-    f32x4 s[4][4];
+    f32x4 s[QT][4];
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
       bf16x8 kf[2];
@@ -304,17 +325,18 @@ __global__ __launch_bounds__(256) void k_attention(
         kf[ks] = *reinterpret_cast<const bf16x8*>(
             &sK[(kt * 16 + fr) * LDD + ks * 32 + fg * 8]);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < QT; ++i) {
         f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
         a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[0], qf[i][0], a, 0, 0, 0);
         a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[1], qf[i][1], a, 0, 0, 0);
         s[i][kt] = a;
       }
     }
-    // bias, key mask, online softmax (statistics per q = fr, lane-local after
-    // a 4-group shuffle reduction)
+    // bias, key mask, online softmax in the log2 domain (statistics per q = fr,
+    // lane-local after a 4-group shuffle reduction)
+    const bool tail = k0 + AK > T;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < QT; ++i) {
       const int q = q0 + i * 16 + fr;
       float mx = -INFINITY;
 #pragma unroll
@@ -324,20 +346,22 @@ __global__ __launch_bounds__(256) void k_attention(
           const int key = k0 + kt * 16 + fg * 4 + r;
           float v = s[i][kt][r];
           if (brow != nullptr && q < T && key < T) v += brow[(int64_t)q * T + key];
-          if (key >= T) v = -INFINITY;
+          v *= kLog2e;
+          if (tail && key >= T) v = -INFINITY;
           s[i][kt][r] = v;
           mx = fmaxf(mx, v);
         }
       mx = fmaxf(mx, __shfl_xor(mx, 16));
       mx = fmaxf(mx, __shfl_xor(mx, 32));
       const float mnew = fmaxf(mrow[i], mx);
-      const float corr = (mrow[i] == -INFINITY) ? 0.f : __expf(mrow[i] - mnew);
+      const float msafe = (mnew == -INFINITY) ? 0.f : mnew;
+      const float corr = __builtin_amdgcn_exp2f(mrow[i] - msafe);
       float rs = 0.f;
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float p = (mnew == -INFINITY) ? 0.f : __expf(s[i][kt][r] - mnew);
+          const float p = __builtin_amdgcn_exp2f(s[i][kt][r] - msafe);
           s[i][kt][r] = p;
           rs += p;
         }
@@ -356,9 +380,9 @@ __global__ __launch_bounds__(256) void k_attention(
     //   j >= 4: key tile 2*kk+1, keys 4fg + (j-4)
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      bf16x8 pf[4];
+      bf16x8 pf[QT];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < QT; ++i) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           pf[i][r] = (short)f2bf(s[i][2 * kk][r]);
@@ -367,22 +391,24 @@ __global__ __launch_bounds__(256) void k_attention(
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        // V^T fragment: row d = j*16 + fr, the same key permutation
-        const bf16_t* vr = &sVt[(j * 16 + fr) * LDT];
-        const bf16x4 v0 = *reinterpret_cast<const bf16x4*>(vr + (2 * kk) * 16 + fg * 4);
-        const bf16x4 v1 = *reinterpret_cast<const bf16x4*>(vr + (2 * kk + 1) * 16 + fg * 4);
+        // V^T fragment of d tile j: column d = j*16 + fr of keys {4fg..4fg+3} of
+        // key tiles 2kk and 2kk+1, delivered by the transposing read
+        const bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (lds_bf16x4*)(&sV[(2 * kk) * 16 * LDD + j * 16 + tr_off]));
+        const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (lds_bf16x4*)(&sV[(2 * kk + 1) * 16 * LDD + j * 16 + tr_off]));
         bf16x8 vf;
         vf[0] = v0[0]; vf[1] = v0[1]; vf[2] = v0[2]; vf[3] = v0[3];
         vf[4] = v1[0]; vf[5] = v1[1]; vf[6] = v1[2]; vf[7] = v1[3];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < QT; ++i)
           o[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[i], o[i][j], 0, 0, 0);
       }
     }
   }
   // normalise and store: lane owns O[q = fr][d = j*16 + 4fg .. +3]
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < QT; ++i) {
     const int q = q0 + i * 16 + fr;
     if (q >= T) continue;
     const float inv = lrow[i] > 0.f ? 1.f / lrow[i] : 0.f;
