@@ -1,0 +1,82 @@
+"""CLIP residual-attention block restatement.  PARITY UNPINNED at the reference
+level: the arithmetic lives in third-party open_clip (absent, unpinned version,
+SURVEY 8c) and the reference holds no vectors for it.  What is checked:
+(CPU) the block equals a hand-written nn.MultiheadAttention-semantics formula;
+(GPU) the MFMA path matches the torch fp32 path within bf16 tolerance, with and
+without the dense additive attn_mask of update_remaining_clip_feats."""
+import pytest
+import torch
+
+from veon_amd.models.semantic_net import clip_blocks
+
+
+def _manual_block(blk, x, mask=None):
+    L, N, D = x.shape
+    H = blk.n_head
+    h = torch.nn.functional.layer_norm(x, (D,), blk.ln_1.weight, blk.ln_1.bias, blk.ln_1.eps)
+    qkv = h @ blk.attn.in_proj_weight.t() + blk.attn.in_proj_bias
+    q, k, v = qkv.view(L, N, 3, H, D // H).permute(2, 1, 3, 0, 4)   # N,H,L,hd
+    s = (q * (D // H) ** -0.5) @ k.transpose(-1, -2)
+    if mask is not None:
+        s = s + mask.view(N, H, L, L)
+    o = (s.softmax(-1) @ v).permute(2, 0, 1, 3).reshape(L, N, D)
+    x = x + o @ blk.attn.out_proj.weight.t() + blk.attn.out_proj.bias
+    h = torch.nn.functional.layer_norm(x, (D,), blk.ln_2.weight, blk.ln_2.bias, blk.ln_2.eps)
+    u = h @ blk.mlp.c_fc.weight.t() + blk.mlp.c_fc.bias
+    u = u * torch.sigmoid(1.702 * u) if blk.quick_gelu else torch.nn.functional.gelu(u)
+    return x + u @ blk.mlp.c_proj.weight.t() + blk.mlp.c_proj.bias
+
+
+@pytest.mark.parametrize('quick', [True, False])
+def test_block_matches_mha_semantics_cpu(quick):
+    torch.manual_seed(0)
+    blk = clip_blocks.ResidualAttentionBlock(128, 2, quick_gelu=quick).eval()
+    x = torch.randn(9, 3, 128)
+    mask = torch.randn(3 * 2, 9, 9)
+    with torch.no_grad():
+        torch.testing.assert_close(blk(x), _manual_block(blk, x), rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(blk(x, attn_mask=mask), _manual_block(blk, x, mask),
+                                   rtol=1e-4, atol=1e-5)
+
+
+def test_trunk_names_and_shapes_cpu():
+    m = clip_blocks.ClipVisualTrunk(image_size=64, patch_size=16, width=64, layers=2,
+                                    heads=1).eval()
+    keys = set(m.state_dict())
+    for k in ('conv1.weight', 'class_embedding', 'positional_embedding',
+              'ln_pre.weight', 'resblocks.0.attn.in_proj_weight',
+              'resblocks.0.attn.out_proj.bias', 'resblocks.1.mlp.c_fc.weight',
+              'resblocks.1.mlp.c_proj.bias', 'resblocks.0.ln_2.bias'):
+        assert k in keys, k
+    with torch.no_grad():
+        outs, hw = m(torch.randn(2, 3, 32, 48))
+    assert hw == (2, 3) and len(outs) == 3 and outs[-1].shape == (7, 2, 64)
+
+
+@pytest.mark.gpu
+def test_clip_b16_blocks_mfma_vs_torch():
+    """ViT-B/16 geometry at 128x352 (the x0.5 image of a 256x704 crop):
+    8x22+1 = 177 tokens, 6 images, 3 blocks; then a tail pass with a dense
+    additive mask."""
+    torch.manual_seed(0)
+    dev = 'cuda:0'
+    m = clip_blocks.ClipVisualTrunk(224, 16, 768, 3, 12).to(dev).eval()
+    img = torch.randn(6, 3, 128, 352, device=dev)
+    with torch.no_grad():
+        outs, hw = m(img)
+        t0 = outs[0]
+        ref = t0
+        for blk in m.resblocks:
+            ref = blk(ref)
+        rel = (outs[-1] - ref).norm() / ref.norm()
+        assert hw == (8, 22) and outs[-1].shape == (177, 6, 768)
+        assert rel < 1e-2, rel.item()
+        L = t0.shape[0]
+        mask = torch.randn(6, 12, L, L, device=dev)
+        masks = [mask.reshape(-1, L, L)] * 3
+        got = clip_blocks.run_blocks(list(m.resblocks), t0, masks)[-1]
+        ref = t0
+        for blk in m.resblocks:
+            ref = blk(ref, attn_mask=masks[0])
+        rel = (got - ref).norm() / ref.norm()
+        assert rel < 1e-2, rel.item()

@@ -1,0 +1,187 @@
+"""CLIP ViT residual-attention blocks of SAN-CLIP on the MFMA kernels.
+
+In the reference the CLIP transformer arithmetic is NOT in the tree: it lives in
+third-party ``open_clip`` (``open_clip.transformer.ResidualAttentionBlock`` /
+``VisionTransformer``; version unpinned anywhere in the reference -- SURVEY 8c),
+and VEON only wraps it: ``FeatureExtractor`` runs ``conv1`` / class + position
+embeddings / ``ln_pre`` / the first K ``resblocks``
+(mmdet3d/models/semantic_net/clip_utils/visual.py:57-91) and
+``update_remaining_clip_feats`` runs the tail blocks again over all tokens with
+a dense additive ``attn_mask`` of shape (B*heads, L+1, L+1) (:258-285).
+This module restates the published block
+    x = x + attn(ln_1(x), attn_mask);  x = x + mlp(ln_2(x))
+with ``nn.MultiheadAttention``'s packed ``in_proj_weight`` / ``in_proj_bias`` /
+``out_proj`` and ``mlp.c_fc`` / ``mlp.c_proj`` parameter names (what an
+``open_clip`` checkpoint holds), QuickGELU for OpenAI weights.
+**Parity unpinned**: ``open_clip`` is not installed and the reference holds no
+vectors for it; tests compare against ``torch.nn.MultiheadAttention`` semantics.
+The 100-query cross attention with the extra "self" logit
+(attn_helper.py:34-300) stays in PyTorch for now.
+"""
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ... import vit_ops
+
+
+class QuickGELU(nn.Module):
+    def forward(self, x):
+        return x * torch.sigmoid(1.702 * x)
+
+
+class ResidualAttentionBlock(nn.Module):
+    def __init__(self, d_model, n_head, mlp_ratio=4.0, quick_gelu=True):
+        super().__init__()
+        self.ln_1 = nn.LayerNorm(d_model)
+        self.attn = nn.MultiheadAttention(d_model, n_head)
+        self.ls_1 = nn.Identity()
+        self.ln_2 = nn.LayerNorm(d_model)
+        width = int(d_model * mlp_ratio)
+        self.mlp = nn.Sequential(OrderedDict([
+            ('c_fc', nn.Linear(d_model, width)),
+            ('gelu', QuickGELU() if quick_gelu else nn.GELU()),
+            ('c_proj', nn.Linear(width, d_model))]))
+        self.ls_2 = nn.Identity()
+        self.n_head = n_head
+        self.quick_gelu = quick_gelu
+
+    def forward(self, x, attn_mask=None):
+        """x (L, N, D) sequence-first, attn_mask additive (N*heads, L, L) or
+        (L, L), as open_clip passes it."""
+        h = self.ln_1(x)
+        a = self.attn(h, h, h, need_weights=False, attn_mask=attn_mask)[0]
+        x = x + self.ls_1(a)
+        return x + self.ls_2(self.mlp(self.ln_2(x)))
+
+
+class _HipClipWeights:
+    def __init__(self, blk):
+        a = blk.attn
+        d = a.embed_dim
+        scale = (d // a.num_heads) ** -0.5
+        w = a.in_proj_weight.detach().float().clone()
+        b = a.in_proj_bias.detach().float().clone()
+        w[:d] *= scale       # F.multi_head_attention_forward scales q
+        b[:d] *= scale
+        self.heads = a.num_heads
+        self.w_qkv, self.b_qkv = vit_ops.to_bf16(w), b.contiguous()
+        self.w_proj = vit_ops.to_bf16(a.out_proj.weight.detach().float())
+        self.b_proj = a.out_proj.bias.detach().float().contiguous()
+        self.w_fc1 = vit_ops.to_bf16(blk.mlp.c_fc.weight.detach().float())
+        self.b_fc1 = blk.mlp.c_fc.bias.detach().float().contiguous()
+        self.w_fc2 = vit_ops.to_bf16(blk.mlp.c_proj.weight.detach().float())
+        self.b_fc2 = blk.mlp.c_proj.bias.detach().float().contiguous()
+        self.n1 = (blk.ln_1.weight.detach().float().contiguous(),
+                   blk.ln_1.bias.detach().float().contiguous(), blk.ln_1.eps)
+        self.n2 = (blk.ln_2.weight.detach().float().contiguous(),
+                   blk.ln_2.bias.detach().float().contiguous(), blk.ln_2.eps)
+        self.act = vit_ops.EPI_QUICKGELU if blk.quick_gelu else vit_ops.EPI_GELU
+
+
+def hip_clip_block(x, w, B, T, bias=None):
+    """One block on the fp32 stream x [B*T, d] (batch-major), in place.
+    bias: optional fp32 [B|1, H|1, T, T] additive logits."""
+    h = vit_ops.layernorm(x, *w.n1)
+    qkv = vit_ops.linear(h, w.w_qkv, w.b_qkv)
+    o = vit_ops.attention(qkv.view(B, T, -1), w.heads, bias)
+    vit_ops.linear_residual_(x, o.view(B * T, -1), w.w_proj, w.b_proj, None)
+    h = vit_ops.layernorm(x, *w.n2)
+    u = vit_ops.linear(h, w.w_fc1, w.b_fc1, w.act)
+    vit_ops.linear_residual_(x, u, w.w_fc2, w.b_fc2, None)
+    return x
+
+
+def run_blocks(blocks, x_lnd, attn_masks=None, cache=None):
+    """Run ``blocks`` over x (L, N, D).  On a ROCm device in no-grad eval mode
+    the MFMA kernels are used (one transpose in, one out); otherwise the torch
+    blocks.  attn_masks: None or one additive mask per block, each
+    (N*heads, L, L) / (N, heads, L, L) / (L, L).  Returns the list of per-block
+    outputs (L, N, D)."""
+    L, N, D = x_lnd.shape
+    hip = (x_lnd.is_cuda and not torch.is_grad_enabled()
+           and not any(b.training for b in blocks)
+           and D % 64 == 0 and all(D // b.n_head == 64 for b in blocks))
+    outs = []
+    if not hip:
+        x = x_lnd
+        for i, blk in enumerate(blocks):
+            m = None if attn_masks is None else attn_masks[i]
+            if m is not None and m.dim() == 4:
+                m = m.reshape(-1, L, L)
+            x = blk(x, attn_mask=m)
+            outs.append(x)
+        return outs
+    if cache is None:
+        cache = {}
+    # private batch-major fp32 copy of the stream (the kernels update it in place)
+    s = torch.empty((N, L, D), dtype=torch.float32, device=x_lnd.device)
+    s.copy_(x_lnd.permute(1, 0, 2))
+    s = s.view(N * L, D)
+    for i, blk in enumerate(blocks):
+        w = cache.get(id(blk))
+        if w is None:
+            w = cache[id(blk)] = _HipClipWeights(blk)
+        m = None if attn_masks is None else attn_masks[i]
+        if m is not None:
+            m = m.float()
+            if m.dim() == 2:
+                m = m.view(1, 1, L, L)
+            elif m.dim() == 3:
+                m = m.view(N, -1, L, L)
+            m = m.contiguous()
+        hip_clip_block(s, w, N, L, m)
+        outs.append(s.view(N, L, D).permute(1, 0, 2).contiguous())
+    return outs
+
+
+class ClipVisualTrunk(nn.Module):
+    """conv1 patchify + class / position embeddings + ln_pre + resblocks: what
+    ``FeatureExtractor.forward`` runs (clip_utils/visual.py:57-91), with
+    open_clip's VisionTransformer parameter names."""
+
+    def __init__(self, image_size=224, patch_size=16, width=768, layers=12,
+                 heads=12, mlp_ratio=4.0, quick_gelu=True):
+        super().__init__()
+        self.grid_size = (image_size // patch_size, image_size // patch_size)
+        self.patch_size = patch_size
+        self.conv1 = nn.Conv2d(3, width, patch_size, patch_size, bias=False)
+        scale = width ** -0.5
+        self.class_embedding = nn.Parameter(scale * torch.randn(width))
+        self.positional_embedding = nn.Parameter(
+            scale * torch.randn(self.grid_size[0] * self.grid_size[1] + 1, width))
+        self.ln_pre = nn.LayerNorm(width)
+        self.resblocks = nn.ModuleList(
+            [ResidualAttentionBlock(width, heads, mlp_ratio, quick_gelu)
+             for _ in range(layers)])
+        self._hip_cache = {}
+
+    def train(self, mode=True):
+        self._hip_cache = {}
+        return super().train(mode)
+
+    def _pos_embed(self, h, w):
+        pe = self.positional_embedding
+        if (h, w) == self.grid_size:
+            return pe
+        cls, grid = pe[:1], pe[1:]
+        grid = grid.reshape(1, self.grid_size[0], self.grid_size[1], -1).permute(0, 3, 1, 2)
+        grid = F.interpolate(grid, size=(h, w), mode='bicubic', align_corners=False)
+        return torch.cat([cls, grid.permute(0, 2, 3, 1).reshape(h * w, -1)], 0)
+
+    def tokens(self, x):
+        x = self.conv1(x)
+        _, _, h, w = x.shape
+        x = x.flatten(2).permute(0, 2, 1)
+        cls = self.class_embedding.to(x.dtype).expand(x.shape[0], 1, -1)
+        x = torch.cat([cls, x], dim=1) + self._pos_embed(h, w).to(x.dtype)
+        return self.ln_pre(x).permute(1, 0, 2), (h, w)     # LND
+
+    def forward(self, x, last_layer_idx=-1, attn_masks=None):
+        """-> (list of per-block token tensors (L,N,D), (h, w))."""
+        t, hw = self.tokens(x)
+        blocks = list(self.resblocks if last_layer_idx == -1
+                      else self.resblocks[:last_layer_idx])
+        return [t] + run_blocks(blocks, t, attn_masks, self._hip_cache), hw
