@@ -93,58 +93,75 @@ __global__ __launch_bounds__(256) void k_layernorm(
 
 // ----------------------------------------------------------------------- GEMM
 // 128x128 output tile, BK = 64, 256 threads = 4 waves in 2(M) x 2(N), each wave
-// 64 tokens x 64 features = 4x4 MFMA tiles.  Operands staged global -> regs ->
-// LDS (rows padded to 72 bf16 = 144 B: conflict-free 16-B fragment reads),
-// double-buffered so the next K-slab's loads fly under the MFMAs.
-constexpr int BM = 128, BN = 128, BK = 64, LDK = BK + 8;
+// 64 tokens x 64 features = 4x4 MFMA tiles.  Operands go global -> LDS directly
+// (global_load_lds_dwordx4: no VGPR staging, 1 KiB per wave instruction) into a
+// double-buffered image whose 16-byte chunks are XOR-swizzled by the row
+// (chunk ^= row & 7): the DMA writes LDS linearly, so the permutation is applied
+// to the per-lane SOURCE address, and again on the fragment reads, which makes
+// every ds_read_b128 of the 16x16x32 operand maps bank-conflict free.
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_ELEMS = BM * BK;  // per operand per buffer (16 KiB)
 
 enum { EPI_BF16 = 0, EPI_GELU = 1, EPI_QUICKGELU = 2, EPI_RESID = 3 };
 
+// erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below the bf16
+// rounding of the output): one rcp, one exp, five FMAs instead of libm's erff.
+__device__ __forceinline__ float erf_as(float x) {
+  const float ax = fabsf(x);
+  const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float y = 1.f - p * t * __expf(-ax * ax);
+  return copysignf(y, x);
+}
 __device__ __forceinline__ float gelu_erf(float x) {
-  return 0.5f * x * (1.f + erff(x * 0.70710678118654752f));
+  return 0.5f * x * (1.f + erf_as(x * 0.70710678118654752f));
 }
 __device__ __forceinline__ float quick_gelu(float x) {
   return x / (1.f + __expf(-1.702f * x));
 }
+
+typedef const void __attribute__((address_space(1))) * gptr_t;
+typedef void __attribute__((address_space(3))) * lptr_t;
 
 template <int EPI>
 __global__ __launch_bounds__(256) void k_gemm_bf16(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
     const float* __restrict__ bias, const float* __restrict__ gamma,
     float* __restrict__ resid, bf16_t* __restrict__ out, int M, int N, int K) {
-  __shared__ __attribute__((aligned(16))) bf16_t sA[2][BM * LDK];
-  __shared__ __attribute__((aligned(16))) bf16_t sW[2][BN * LDK];
+  // one array for all staging (a second __shared__ object beside a DMA target
+  // can make hipcc drain vmcnt before every ds_read: guide section 5 item 4a)
+  __shared__ __attribute__((aligned(16))) bf16_t smem[4 * TILE_ELEMS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   const int fr = lane & 15, fg = lane >> 4;
 
-  // staging map: 128 rows x 64 k = 1024 chunks of 8 bf16; 4 per thread
-  bf16x8 ra[4], rw[4];
-  auto load_tiles = [&](int k0) {
+  // DMA map: wave instruction j (0..3) of wave w fills LDS chunks
+  // [(w*4 + j)*64, +64) of a tile = rows (w*4 + j)*8 .. +8; lane l lands in row
+  // r = base + l/8, physical chunk l%8, so it must fetch logical chunk
+  // (l%8) ^ (r&7).  Rows beyond M / N are clamped (their outputs are dropped).
+  const bf16_t* srcA[4];
+  const bf16_t* srcW[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int ch = tid + i * 256;
-      const int r = ch >> 3, kc = (ch & 7) * 8;
-      const int gm = m0 + r;
-      if (gm < M)
-        ra[i] = *reinterpret_cast<const bf16x8*>(A + (int64_t)gm * K + k0 + kc);
-      else
-        ra[i] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-      const int gn = n0 + r;
-      if (gn < N)
-        rw[i] = *reinterpret_cast<const bf16x8*>(W + (int64_t)gn * K + k0 + kc);
-      else
-        rw[i] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-    }
-  };
-  auto store_tiles = [&](int buf) {
+  for (int j = 0; j < 4; ++j) {
+    const int r = (wave * 4 + j) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ (r & 7);
+    const int gm = m0 + r < M ? m0 + r : M - 1;
+    const int gn = n0 + r < N ? n0 + r : N - 1;
+    srcA[j] = A + (int64_t)gm * K + c * 8;
+    srcW[j] = W + (int64_t)gn * K + c * 8;
+  }
+  auto dma = [&](int buf, int k0) {
+    bf16_t* dA = smem + buf * 2 * TILE_ELEMS;
+    bf16_t* dW = dA + TILE_ELEMS;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int ch = tid + i * 256;
-      const int r = ch >> 3, kc = (ch & 7) * 8;
-      *reinterpret_cast<bf16x8*>(&sA[buf][r * LDK + kc]) = ra[i];
-      *reinterpret_cast<bf16x8*>(&sW[buf][r * LDK + kc]) = rw[i];
+    for (int j = 0; j < 4; ++j) {
+      const int slot = (wave * 4 + j) * 512;  // bf16 elements: 64 lanes x 8
+      __builtin_amdgcn_global_load_lds((gptr_t)(srcA[j] + k0), (lptr_t)(dA + slot), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(srcW[j] + k0), (lptr_t)(dW + slot), 16, 0, 0);
     }
   };
 
@@ -154,24 +171,33 @@ __global__ __launch_bounds__(256) void k_gemm_bf16(
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  load_tiles(0);
-  store_tiles(0);
-  __syncthreads();
+  // fragment read offsets (bf16 elements) for ks = 0; ks = 1 flips chunk bit 2
+  int offA[4], offW[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int ra = wm * 64 + i * 16 + fr;
+    const int rw = wn * 64 + i * 16 + fr;
+    offA[i] = ra * BK + ((fg ^ (ra & 7)) * 8);
+    offW[i] = rw * BK + ((fg ^ (rw & 7)) * 8);
+  }
+
   const int nk = K / BK;
+  dma(0, 0);
+  __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
-    if (kt + 1 < nk) load_tiles((kt + 1) * BK);
+    if (kt + 1 < nk) dma(buf ^ 1, (kt + 1) * BK);
+    const bf16_t* tA = smem + buf * 2 * TILE_ELEMS;
+    const bf16_t* tW = tA + TILE_ELEMS;
 #pragma unroll
     for (int ks = 0; ks < BK / 32; ++ks) {
       bf16x8 fa[4], fw[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i)
-        fa[i] = *reinterpret_cast<const bf16x8*>(
-            &sA[buf][(wm * 64 + i * 16 + fr) * LDK + ks * 32 + fg * 8]);
+        fa[i] = *reinterpret_cast<const bf16x8*>(tA + (offA[i] ^ (ks * 32)));
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        fw[j] = *reinterpret_cast<const bf16x8*>(
-            &sW[buf][(wn * 64 + j * 16 + fr) * LDK + ks * 32 + fg * 8]);
+        fw[j] = *reinterpret_cast<const bf16x8*>(tW + (offW[j] ^ (ks * 32)));
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -181,8 +207,7 @@ __global__ __launch_bounds__(256) void k_gemm_bf16(
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i],
                                                                acc[i][j], 0, 0, 0);
     }
-    if (kt + 1 < nk) store_tiles(buf ^ 1);
-    __syncthreads();
+    __syncthreads();  // next slab landed (vmcnt drained) and this one released
   }
 
   // epilogue: lane owns 4 consecutive features of one token per tile
