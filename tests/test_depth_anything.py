@@ -104,3 +104,21 @@ def test_gpu_vitb_shape_mfma_vs_torch_fp32():
         b = enc.forward_features(x)['x_prenorm']
     rel = (a - b).norm() / b.norm()
     assert a.shape == (2, 901, 768) and rel < 1e-2, rel.item()
+
+
+@pytest.mark.gpu
+def test_encoder_is_graph_capturable():
+    from veon_amd.graphs import GraphedCallable
+    g = load_golden('dinov2_tiny')
+    enc, head = _build(g)
+    enc = enc.to('cuda:0')
+    x = torch.from_numpy(g['x']).to('cuda:0')
+    with torch.no_grad():
+        want = enc.forward_features(x)['x_prenorm'].clone()
+    graphed = GraphedCallable(lambda im: enc.forward_features(im)['x_prenorm'], (x,))
+    got = graphed(x).clone()
+    assert torch.equal(got, want)
+    got2 = graphed(x * 0.5).clone()
+    with torch.no_grad():
+        want2 = enc.forward_features(x * 0.5)['x_prenorm']
+    assert torch.equal(got2, want2)

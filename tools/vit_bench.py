@@ -10,6 +10,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from veon_amd import vit_ops  # noqa: E402
 from veon_amd.models.depth_anything import dinov2  # noqa: E402
+from veon_amd.graphs import GraphedCallable  # noqa: E402
 
 PEAK = 2500.0  # TFLOP/s dense bf16, MI355X_MICROARCH.md
 
@@ -73,6 +74,10 @@ def main():
             nb = len(enc.blocks)
             print('  encoder (%d blocks, 6 imgs)    %8.1f us  %6.1f TF/s  -> %.1f 6-cam samples/s'
                   % (nb, us, nb * blk_fl / us / 1e6, 1e6 / us))
+            g = GraphedCallable(lambda im: enc.forward_features(im)['x_prenorm'], (img,))
+            gus = timeit(lambda: g(img), iters=20)
+            print('  encoder, hipGraph replay       %8.1f us  %6.1f TF/s  -> %.1f 6-cam samples/s'
+                  % (gus, nb * blk_fl / gus / 1e6, 1e6 / gus))
             enc.use_hip = False
             enc16 = enc.bfloat16()
             tus = timeit(lambda: enc16.forward_features(img.bfloat16()), iters=10)
