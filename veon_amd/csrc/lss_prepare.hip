@@ -11,7 +11,8 @@
 //   k_scan_*       exclusive scan of the histogram over all voxels (3 kernels),
 //                  emits interval_starts / interval_lengths, counts and the
 //                  64-voxel tile plan of the fused pool kernels
-//   k_scatter      points -> their voxel's slot range (atomic cursor)
+//   k_scatter      points -> their voxel's slot range (slot = the arrival index
+//                  the histogram atomic returned; no second atomic pass)
 //   k_rank_in_bin  deterministic stable order inside every interval
 //                  (ascending point index) by rank-counting
 //
@@ -122,14 +123,15 @@ __global__ __launch_bounds__(kBlock) void k_camera_matrices(
 }
 
 __global__ __launch_bounds__(kBlock) void k_lidar_coor(
-    Geometry g, int N, int D, int H, int W, int64_t P,
-    float* __restrict__ coor) {
-  const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (p >= P) return;
-  const int w = (int)(p % W);
-  const int h = (int)((p / W) % H);
-  const int d = (int)((p / ((int64_t)W * H)) % D);
-  const int bn = (int)(p / ((int64_t)W * H * D));
+    Geometry g, int N, int D, int H, int W, float* __restrict__ coor) {
+  const int bn = blockIdx.y;
+  const int dhw = D * H * W;
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= dhw) return;
+  const int64_t p = (int64_t)bn * dhw + i;
+  const int w = i % W;
+  const int h = (i / W) % H;
+  const int d = i / (W * H);
   float o[3];
   point_coor(g, bn, bn / N, d, h, w, o);
   coor[p * 3 + 0] = o[0];
@@ -155,30 +157,34 @@ __device__ __forceinline__ int voxel_key(const GridF& gr, const float* c,
   return (int)r;
 }
 
+// grid = (points of one camera / kBlock, B*N cameras): the camera index is
+// workgroup-uniform, so the 3x3 matrices come in by scalar loads.  The
+// returning histogram atomic doubles as the point's arrival slot in its voxel.
 template <bool FROM_COOR>
 __global__ __launch_bounds__(kBlock) void k_voxel_keys(
     Geometry g, const float* __restrict__ coor, GridF gr, int N, int D, int H,
-    int W, int64_t P, int64_t n_bins, int* __restrict__ keys,
+    int W, int64_t n_bins, int* __restrict__ keys, int* __restrict__ slots,
     int* __restrict__ hist) {
-  const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (p >= P) return;
-  const int64_t per_b = (int64_t)N * D * H * W;
+  const int bn = blockIdx.y;
+  const int dhw = D * H * W;
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= dhw) return;
+  const int64_t p = (int64_t)bn * dhw + i;
   float c[3];
   if (FROM_COOR) {
     c[0] = coor[p * 3 + 0];
     c[1] = coor[p * 3 + 1];
     c[2] = coor[p * 3 + 2];
   } else {
-    const int w = (int)(p % W);
-    const int h = (int)((p / W) % H);
-    const int d = (int)((p / ((int64_t)W * H)) % D);
-    const int bn = (int)(p / ((int64_t)W * H * D));
+    const int w = i % W;
+    const int h = (i / W) % H;
+    const int d = i / (W * H);
     point_coor(g, bn, bn / N, d, h, w, c);
   }
-  int key = voxel_key(gr, c, p / per_b);
+  int key = voxel_key(gr, c, bn / N);
   if (key >= n_bins) key = -1;  // cannot happen for consistent grids; be safe
   keys[p] = key;
-  if (key >= 0) atomicAdd(hist + key, 1);
+  if (key >= 0) slots[p] = atomicAdd(hist + key, 1);
 }
 
 // ---- exclusive scan over the histogram (count and non-empty flag) ----------
@@ -321,16 +327,16 @@ __global__ __launch_bounds__(kBlock) void k_scan_emit(
   }
 }
 
-// points -> slots of their voxel (order inside the voxel fixed by k_rank_in_bin)
+// points -> slot range of their voxel, at the arrival slot the histogram atomic
+// handed out (order inside the voxel is then fixed by k_rank_in_bin)
 __global__ __launch_bounds__(kBlock) void k_scatter(
-    const int* __restrict__ keys, int64_t P, const int* __restrict__ bin_start,
-    int* __restrict__ cursor, int* __restrict__ tmp_point) {
+    const int* __restrict__ keys, const int* __restrict__ slots, int64_t P,
+    const int* __restrict__ bin_start, int* __restrict__ tmp_point) {
   const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (p >= P) return;
   const int key = keys[p];
   if (key < 0) return;
-  const int slot = bin_start[key] + atomicAdd(cursor + key, 1);
-  tmp_point[slot] = (int)p;
+  tmp_point[bin_start[key] + slots[p]] = (int)p;
 }
 
 // stable order inside each interval: final slot = start + #points of the
@@ -361,9 +367,9 @@ inline int launch_status() {
 
 struct Workspace {
   int* keys;       // [P]
+  int* slots;      // [P]  arrival index of the point inside its voxel
   int* tmp_point;  // [P]
   int* hist;       // [n_bins]      (zeroed per call)
-  int* cursor;     // [n_bins]      (zeroed per call; contiguous with hist)
   int* bin_start;  // [n_bins]
   Pair* block_sums;  // [n_scan_blocks]
   int64_t bytes;
@@ -381,9 +387,9 @@ inline Workspace carve(void* base, int64_t P, int64_t n_bins) {
     return r;
   };
   w.keys = reinterpret_cast<int*>(take(P * 4));
+  w.slots = reinterpret_cast<int*>(take(P * 4));
   w.tmp_point = reinterpret_cast<int*>(take(P * 4));
-  w.hist = reinterpret_cast<int*>(take(n_bins * 4 * 2));
-  w.cursor = w.hist ? w.hist + n_bins : nullptr;
+  w.hist = reinterpret_cast<int*>(take(n_bins * 4));
   w.bin_start = reinterpret_cast<int*>(take(n_bins * 4));
   const int64_t n_scan_blocks = (n_bins + kScanBlock - 1) / kScanBlock;
   w.block_sums = reinterpret_cast<Pair*>(take(n_scan_blocks * (int64_t)sizeof(Pair)));
@@ -418,11 +424,13 @@ int veon_lidar_coor(int B, int N, int D, int H, int W, const float* xs,
       !bda || !coor)
     return VEON_ERR_BAD_ARG;
   const int64_t P = (int64_t)B * N * D * H * W;
-  if (P > 0x7fffffffLL) return VEON_ERR_BAD_ARG;
+  if (P > 0x7fffffffLL || B * N > 65535) return VEON_ERR_BAD_ARG;
   Geometry g{xs, ys, ds, post_rots_inv, post_trans, combine, trans, bda};
-  hipLaunchKernelGGL(k_lidar_coor, dim3((unsigned)((P + kBlock - 1) / kBlock)),
+  const int64_t dhw = (int64_t)D * H * W;
+  hipLaunchKernelGGL(k_lidar_coor,
+                     dim3((unsigned)((dhw + kBlock - 1) / kBlock), (unsigned)(B * N)),
                      dim3(kBlock), 0, static_cast<hipStream_t>(stream), g, N, D,
-                     H, W, P, coor);
+                     H, W, coor);
   return launch_status();
 }
 
@@ -453,7 +461,8 @@ int veon_lss_prepare(int B, int N, int D, int H, int W, const float* coor,
     return VEON_ERR_BAD_ARG;
   const int64_t P = (int64_t)B * N * D * H * W;
   const int64_t n_bins = voxels_per_batch * B;
-  if (P > 0x7fffffffLL || n_bins > 0x7fffffffLL) return VEON_ERR_BAD_ARG;
+  if (P > 0x7fffffffLL || n_bins > 0x7fffffffLL || B * N > 65535)
+    return VEON_ERR_BAD_ARG;
   // the plan emitted by the scan needs tiles aligned to the scan blocks
   if (plan && (voxels_per_batch % kTileV != 0)) return VEON_ERR_BAD_ARG;
   if (plan && (reinterpret_cast<uintptr_t>(plan) & 15u)) return VEON_ERR_BAD_ARG;
@@ -467,15 +476,17 @@ int veon_lss_prepare(int B, int N, int D, int H, int W, const float* coor,
     gr.size[i] = grid_size[i];
   }
   Geometry g{xs, ys, ds, post_rots_inv, post_trans, combine, trans, bda};
-  if (hipMemsetAsync(w.hist, 0, (size_t)n_bins * 8, s) != hipSuccess)
+  if (hipMemsetAsync(w.hist, 0, (size_t)n_bins * 4, s) != hipSuccess)
     return VEON_ERR_LAUNCH;
   const unsigned pb = (unsigned)((P + kBlock - 1) / kBlock);
+  const int64_t dhw = (int64_t)D * H * W;
+  const dim3 kgrid((unsigned)((dhw + kBlock - 1) / kBlock), (unsigned)(B * N));
   if (coor)
-    hipLaunchKernelGGL(k_voxel_keys<true>, dim3(pb), dim3(kBlock), 0, s, g, coor,
-                       gr, N, D, H, W, P, n_bins, w.keys, w.hist);
+    hipLaunchKernelGGL(k_voxel_keys<true>, kgrid, dim3(kBlock), 0, s, g, coor,
+                       gr, N, D, H, W, n_bins, w.keys, w.slots, w.hist);
   else
-    hipLaunchKernelGGL(k_voxel_keys<false>, dim3(pb), dim3(kBlock), 0, s, g,
-                       coor, gr, N, D, H, W, P, n_bins, w.keys, w.hist);
+    hipLaunchKernelGGL(k_voxel_keys<false>, kgrid, dim3(kBlock), 0, s, g, coor,
+                       gr, N, D, H, W, n_bins, w.keys, w.slots, w.hist);
   const int n_scan_blocks = (int)((n_bins + kScanBlock - 1) / kScanBlock);
   hipLaunchKernelGGL(k_scan_reduce, dim3(n_scan_blocks), dim3(kBlock), 0, s,
                      w.hist, n_bins, w.block_sums);
@@ -486,8 +497,8 @@ int veon_lss_prepare(int B, int N, int D, int H, int W, const float* coor,
                      w.hist, n_bins, w.block_sums, w.bin_start, interval_starts,
                      interval_lengths, reinterpret_cast<int4*>(plan),
                      voxels_per_batch, tiles_per_batch);
-  hipLaunchKernelGGL(k_scatter, dim3(pb), dim3(kBlock), 0, s, w.keys, P,
-                     w.bin_start, w.cursor, w.tmp_point);
+  hipLaunchKernelGGL(k_scatter, dim3(pb), dim3(kBlock), 0, s, w.keys, w.slots,
+                     P, w.bin_start, w.tmp_point);
   hipLaunchKernelGGL(k_rank_in_bin, dim3(pb), dim3(kBlock), 0, s, w.keys,
                      w.tmp_point, counts, w.bin_start, w.hist, D, H * W,
                      ranks_bev, ranks_depth, ranks_feat);
