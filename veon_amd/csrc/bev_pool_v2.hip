@@ -717,9 +717,9 @@ int veon_bev_pool_v2_fwd_maxpool(int c, int n_intervals, int batch, int Z, int Y
   PoolArgs a{depth, feat, ranks_depth, ranks_feat, ranks_bev, interval_starts,
              interval_lengths};
   const int Xo = X / dx;
-  // channel slab so that the [cs][Xo] key tile stays <= 32 KB
+  // channel slab so that the [cs][Xo] key tile stays <= 16 KB (occupancy first)
   int cs = c;
-  while ((int64_t)cs * Xo * 4 > 32768 && cs > 4) cs = (cs / 2 + 3) / 4 * 4;
+  while ((int64_t)cs * Xo * 4 > 16384 && cs > 4) cs = (cs / 2 + 3) / 4 * 4;
   const int slabs = (c + cs - 1) / cs;
   const bool v4 = (c % 4 == 0) && (cs % 4 == 0) && aligned16(feat);
   const size_t lds = ((size_t)cs * Xo + Xo) * sizeof(int);
