@@ -252,3 +252,41 @@ def test_cpu_tensors_raise():
     with pytest.raises(_lib.VeonHipError):
         ext.bev_pool_v2_forward(*(torch.zeros(1),) * 3,
                                 *(torch.zeros(1, dtype=torch.int32),) * 5)
+
+
+@pytest.mark.parametrize('C', [8, 80])
+def test_very_long_intervals_and_dense_tiles(C):
+    """Edge cases of the fused kernels' staging logic: one interval longer than
+    the staged window (3000 > 1024 points), a tile whose points need several
+    windows, a tile with all 64 voxels occupied (two 32-voxel halves when the
+    compact LDS tile has 32 columns) and intervals straddling window ends."""
+    rng = np.random.default_rng(7 + C)
+    B, Z, Y, X = 1, 2, 8, 32            # 512 voxels = 8 tiles of 64
+    nvox = B * Z * Y * X
+    lens = np.zeros(nvox, np.int64)
+    lens[5] = 3000                       # > window
+    lens[64:128] = rng.integers(1, 40, 64)    # dense tile, ~1300 points
+    lens[130] = 1024                     # exactly one window
+    lens[131] = 1025
+    lens[200:260:3] = rng.integers(1, 5, 20)  # sparse, crosses a tile boundary
+    lens[511] = 7                        # last voxel
+    rb = np.repeat(np.arange(nvox), lens).astype(np.int32)
+    n = len(rb)
+    n_depth, n_feat = 997, 211
+    rd = rng.integers(0, n_depth, n).astype(np.int32)
+    rf = rng.integers(0, n_feat, n).astype(np.int32)
+    st, ln = helpers.bp_intervals(rb)
+    depth = rng.random((1, 1, n_depth, 1, 1), dtype=np.float32)
+    feat = rng.standard_normal((1, 1, n_feat, 1, C)).astype(np.float32)
+    shape = (B, Z, Y, X, C)
+    ranks = (rb, rd, rf, st, ln)
+    want = _oracle_out(depth, feat, ranks, shape)
+    assert np.array_equal(_run_scatter(depth, feat, ranks, shape), want)
+    assert np.array_equal(_run_fused(depth, feat, ranks, shape, _lib.LAYOUT_BZYXC), want)
+    assert np.array_equal(_run_fused(depth, feat, ranks, shape, _lib.LAYOUT_BCZYX, True),
+                          want.transpose(0, 4, 1, 2, 3))
+    # fused max-pool on the same case
+    got = bp.bev_pool_v2_maxpool(dev(depth), dev(feat), dev(rd), dev(rf), dev(rb),
+                                 shape, dev(st), dev(ln), (2, 2, 2))
+    full = want.transpose(0, 4, 1, 2, 3)
+    assert np.array_equal(got.cpu().numpy(), c_oracle.maxpool3d(full, (2, 2, 2)))
