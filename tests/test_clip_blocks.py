@@ -80,3 +80,36 @@ def test_clip_b16_blocks_mfma_vs_torch():
             ref = blk(ref, attn_mask=masks[0])
         rel = (got - ref).norm() / ref.norm()
         assert rel < 1e-2, rel.item()
+
+
+def test_cross_attn_with_self_bias_equals_augmented_softmax():
+    """Independent formulation: append every query to its own key/value list
+    (one extra key per query) and run an ordinary masked softmax attention."""
+    torch.manual_seed(1)
+    D, H, K, L, N = 128, 2, 5, 11, 3
+    blk = clip_blocks.ResidualAttentionBlock(D, H).eval()
+    x, mem = torch.randn(K, N, D), torch.randn(L, N, D)
+    bias = torch.randn(N * H, K, L)
+    with torch.no_grad():
+        got = clip_blocks.cross_attn_layer(blk, x, mem, bias)
+        a = blk.attn
+        hd = D // H
+        qx, mx = blk.ln_1(x), blk.ln_1(mem)
+        w, b = a.in_proj_weight, a.in_proj_bias
+        ref_rows = []
+        for n in range(N):
+            per_q = []
+            for kq in range(K):
+                keys = torch.cat([mx[:, n], qx[kq:kq + 1, n]], 0)      # L+1 tokens
+                q = (qx[kq, n] @ w[:D].t() + b[:D]).view(H, hd) * hd ** -0.5
+                kk = (keys @ w[D:2 * D].t() + b[D:2 * D]).view(L + 1, H, hd)
+                vv = (keys @ w[2 * D:].t() + b[2 * D:]).view(L + 1, H, hd)
+                logit = torch.einsum('hd,lhd->hl', q, kk)
+                logit[:, :L] += bias.view(N, H, K, L)[n, :, kq]
+                o = torch.einsum('hl,lhd->hd', logit.softmax(-1), vv).reshape(D)
+                per_q.append(o @ a.out_proj.weight.t() + a.out_proj.bias)
+            ref_rows.append(torch.stack(per_q))
+        attn_out = torch.stack(ref_rows, 1)                             # K,N,D
+        ref = x + attn_out
+        ref = ref + blk.mlp(blk.ln_2(ref))
+    torch.testing.assert_close(got, ref, rtol=1e-4, atol=1e-5)

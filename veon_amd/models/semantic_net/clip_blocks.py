@@ -57,6 +57,52 @@ class ResidualAttentionBlock(nn.Module):
         return x + self.ls_2(self.mlp(self.ln_2(x)))
 
 
+def cross_attn_with_self_bias(attn, query, key, value, attn_mask=None):
+    """The SOS/query-token attention of SAN's ``RecWithAttnbiasHead``
+    (mmdet3d/models/semantic_net/attn_helper.py:34-300, called from
+    ``cross_attn_layer`` :303-314): queries (K, N, D) attend over the memory
+    tokens (L, N, D) with an additive per-head bias (N*heads, K, L) and, in
+    addition, over THEMSELVES through one extra logit q.k_self whose value is
+    the query's own v projection -- a softmax over L + 1 logits per query.
+    ``attn`` is an nn.MultiheadAttention holding the packed projections.
+    PyTorch implementation (100 queries: not a hot loop)."""
+    K, N, D = query.shape
+    L = key.shape[0]
+    H = attn.num_heads
+    hd = D // H
+    w, b = attn.in_proj_weight, attn.in_proj_bias
+    q = F.linear(query, w[:D], b[:D]) * hd ** -0.5
+    k = F.linear(key, w[D:2 * D], b[D:2 * D])
+    v = F.linear(value, w[2 * D:], b[2 * D:])
+    q_k = F.linear(query, w[D:2 * D], b[D:2 * D])   # the query as its own key
+    q_v = F.linear(query, w[2 * D:], b[2 * D:])     # ... and value
+
+    def heads(t):  # (T, N, D) -> (N*H, T, hd)
+        return t.contiguous().view(t.shape[0], N * H, hd).transpose(0, 1)
+    q, k, v, q_k, q_v = heads(q), heads(k), heads(v), heads(q_k), heads(q_v)
+    logits = torch.bmm(q, k.transpose(1, 2))                   # (N*H, K, L)
+    if attn_mask is not None:
+        if attn_mask.dtype == torch.bool:
+            logits = logits.masked_fill(attn_mask, float('-inf'))
+        else:
+            logits = logits + attn_mask
+    self_logit = (q * q_k).sum(dim=-1, keepdim=True)           # (N*H, K, 1)
+    p = F.softmax(torch.cat([logits, self_logit], dim=-1), dim=-1)
+    out = torch.bmm(p[:, :, :-1], v) + p[:, :, -1:] * q_v      # (N*H, K, hd)
+    out = out.transpose(0, 1).contiguous().view(K, N, D)
+    return F.linear(out, attn.out_proj.weight, attn.out_proj.bias)
+
+
+def cross_attn_layer(block, x, mem, attn_bias):
+    """attn_helper.py:303-314: x (K,N,D) queries, mem (L,N,D), attn_bias
+    (N*heads, K, L)."""
+    q_x = block.ln_1(x)
+    k_x = block.ln_1(mem)
+    x = x + block.ls_1(cross_attn_with_self_bias(block.attn, q_x, k_x, k_x,
+                                                 attn_mask=attn_bias))
+    return x + block.ls_2(block.mlp(block.ln_2(x)))
+
+
 class _HipClipWeights:
     def __init__(self, blk):
         a = blk.attn
