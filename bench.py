@@ -71,14 +71,22 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', 1))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a ROCm device (no CPU fallback)')
+    # rehearsal knobs for a ONE-GPU box (never set by the driver): all ranks on
+    # device 0 and the gloo backend, to exercise the N>1 control flow
+    rehearse = os.environ.get('VEON_BENCH_REHEARSAL') == '1'
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world,
-                                device_id=dev)
+        if rehearse:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+        else:
+            dist.init_process_group('nccl', rank=rank, world_size=world,
+                                    device_id=dev)
 
     from veon_amd import _lib, synthetic
     from veon_amd.models import build_neck
@@ -157,7 +165,8 @@ def main():
             dist.barrier()
         elapsed = time.perf_counter() - t0
         if dist is not None:
-            tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            tmax = torch.tensor([elapsed], dtype=torch.float64,
+                                device='cpu' if rehearse else dev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             elapsed = float(tmax.item())
 
