@@ -31,11 +31,8 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef unsigned short bf16_t;
 
 __device__ __forceinline__ bf16_t f2bf(float f) {
-  // round to nearest even; NaN stays NaN
-  unsigned u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
+  // plain cast: hipcc emits v_cvt_pk_bf16_f32 (round to nearest even, NaN kept)
+  return __builtin_bit_cast(bf16_t, (__bf16)f);
 }
 __device__ __forceinline__ float bf2f(bf16_t h) {
   return __uint_as_float(((unsigned)h) << 16);
@@ -295,7 +292,7 @@ __global__ __launch_bounds__(256) void k_attention(
     }
   }
   f32x4 o[QT][4];  // [q tile][d tile]: O^T[d = 4fg + reg][q = fr]
-  float mrow[QT], lrow[QT];  // running max (log2 domain) and sum per q = fr
+  float mrow[QT], lrow[QT];  // running max and sum per q = fr
 #pragma unroll
   for (int i = 0; i < QT; ++i) {
     mrow[i] = -INFINITY;
@@ -357,7 +354,7 @@ __global__ __launch_bounds__(256) void k_attention(
         s[i][kt] = a;
       }
     }
-    // bias, key mask, online softmax in the log2 domain (statistics per q = fr,
+    // bias, key mask, online softmax (statistics per q = fr,
     // lane-local after a 4-group shuffle reduction)
     const bool tail = k0 + AK > T;
 #pragma unroll
@@ -371,7 +368,6 @@ __global__ __launch_bounds__(256) void k_attention(
           const int key = k0 + kt * 16 + fg * 4 + r;
           float v = s[i][kt][r];
           if (brow != nullptr && q < T && key < T) v += brow[(int64_t)q * T + key];
-          v *= kLog2e;
           if (tail && key >= T) v = -INFINITY;
           s[i][kt][r] = v;
           mx = fmaxf(mx, v);
@@ -380,13 +376,15 @@ __global__ __launch_bounds__(256) void k_attention(
       mx = fmaxf(mx, __shfl_xor(mx, 32));
       const float mnew = fmaxf(mrow[i], mx);
       const float msafe = (mnew == -INFINITY) ? 0.f : mnew;
-      const float corr = __builtin_amdgcn_exp2f(mrow[i] - msafe);
+      const float corr = __builtin_amdgcn_exp2f((mrow[i] - msafe) * kLog2e);
+      const float moff = -msafe * kLog2e;
       float rs = 0.f;
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float p = __builtin_amdgcn_exp2f(s[i][kt][r] - msafe);
+          // exp(s - m) = exp2(s*log2e - m*log2e): one FMA + one exp2
+          const float p = __builtin_amdgcn_exp2f(fmaf(s[i][kt][r], kLog2e, moff));
           s[i][kt][r] = p;
           rs += p;
         }
