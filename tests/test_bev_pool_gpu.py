@@ -290,3 +290,69 @@ def test_very_long_intervals_and_dense_tiles(C):
                                  shape, dev(st), dev(ln), (2, 2, 2))
     full = want.transpose(0, 4, 1, 2, 3)
     assert np.array_equal(got.cpu().numpy(), c_oracle.maxpool3d(full, (2, 2, 2)))
+
+
+def _random_case(rng):
+    B = int(rng.integers(1, 4))
+    Z, Y, X = int(rng.integers(1, 5)), int(rng.integers(1, 9)), int(rng.integers(1, 70))
+    C = int(rng.choice([1, 2, 4, 5, 8, 12, 32, 80, 132, 256]))
+    nvox = B * Z * Y * X
+    occ_p = rng.choice([0.02, 0.3, 0.9])
+    heavy = rng.random() < 0.5
+    lens = (rng.random(nvox) < occ_p) * rng.integers(1, 6, nvox)
+    if heavy:
+        hot = rng.integers(0, nvox, size=min(3, nvox))
+        lens[hot] = rng.integers(100, 1500, size=len(hot))
+    rb = np.repeat(np.arange(nvox), lens).astype(np.int32)
+    n = len(rb)
+    n_depth, n_feat = int(rng.integers(1, 400)), int(rng.integers(1, 90))
+    rd = rng.integers(0, n_depth, n).astype(np.int32)
+    rf = rng.integers(0, n_feat, n).astype(np.int32)
+    st, ln = helpers.bp_intervals(rb) if n else (np.zeros(0, np.int32),) * 2
+    depth = rng.random((1, 1, n_depth, 1, 1), dtype=np.float32)
+    feat = rng.standard_normal((1, 1, n_feat, 1, C)).astype(np.float32)
+    return depth, feat, (rb, rd, rf, st, ln), (B, Z, Y, X, C)
+
+
+@pytest.mark.parametrize('seed', range(24))
+def test_random_structures_bit_exact(seed):
+    """Random grids (ragged tiles, odd channel counts, empty / dense / very long
+    intervals, several batch elements): every forward kernel equals the oracle
+    bit for bit, and the fused max-pool equals max-pooling that volume."""
+    rng = np.random.default_rng(1000 + seed)
+    depth, feat, ranks, shape = _random_case(rng)
+    want = _oracle_out(depth, feat, ranks, shape)
+    if len(ranks[0]):
+        assert np.array_equal(_run_scatter(depth, feat, ranks, shape), want)
+    assert np.array_equal(_run_fused(depth, feat, ranks, shape, _lib.LAYOUT_BZYXC), want)
+    cf = _run_fused(depth, feat, ranks, shape, _lib.LAYOUT_BCZYX, bool(seed & 1))
+    assert np.array_equal(cf, want.transpose(0, 4, 1, 2, 3))
+    B, Z, Y, X, C = shape
+    ds = tuple(int(d) for d, n in ((2, Z), (2, Y), (2, X)))
+    ds = tuple(d if n % d == 0 else 1 for d, n in zip(ds, (Z, Y, X)))
+    rb, rd, rf, st, ln = (dev(a) for a in ranks)
+    got = bp.bev_pool_v2_maxpool(dev(depth), dev(feat), rd, rf, rb, shape, st, ln, ds)
+    assert np.array_equal(got.cpu().numpy(), c_oracle.maxpool3d(cf, ds))
+
+
+@pytest.mark.parametrize('seed', range(6))
+def test_random_structures_backward_bit_exact(seed):
+    rng = np.random.default_rng(2000 + seed)
+    depth, feat, ranks, shape = _random_case(rng)
+    rb, rd, rf, st, ln = ranks
+    if len(rb) == 0:
+        pytest.skip('empty case')
+    # every frustum point has its own depth element (ranks_depth is a
+    # permutation in real data); depth_grad is a STORE per point
+    # (bev_pool_cuda.cu:104), so duplicates would race in the reference too
+    n = len(rb)
+    depth = rng.random((1, 1, n + 7, 1, 1), dtype=np.float32)
+    rd = rng.permutation(n + 7)[:n].astype(np.int32)
+    og = rng.standard_normal(shape).astype(np.float32)
+    want_dg, want_fg = helpers.oracle_backward(og, depth, feat, rd, rf, rb)
+    d = dev(depth).requires_grad_()
+    f = dev(feat).requires_grad_()
+    out = bev_pool_v2(d, f, dev(rd), dev(rf), dev(rb), shape, dev(st), dev(ln))
+    out.backward(dev(og.transpose(0, 4, 1, 2, 3)))
+    assert np.array_equal(d.grad.cpu().numpy(), want_dg)
+    assert np.array_equal(f.grad.cpu().numpy(), want_fg)
