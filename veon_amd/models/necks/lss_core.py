@@ -97,7 +97,7 @@ class LSSCore(_Base):
 
     def init_acceleration_v2(self, coor):
         """view_transformer_raw.py:196-215: cache the five rank tensors (plus,
-        here, the fused kernel's tile table)."""
+        here, the fused kernels' tile plan and row table)."""
         ranks_bev, ranks_depth, ranks_feat, interval_starts, interval_lengths \
             = self.voxel_pooling_prepare_v2(coor)
         if ranks_bev is None:
