@@ -362,3 +362,20 @@ def test_hip_depth_prep(name):
     np.testing.assert_allclose(th.cpu().numpy(), want, rtol=1e-5, atol=1e-8)
     # sums to < 1 (last bin dropped) and the two largest bins straddle d
     assert (th.sum(2) <= 1.0 + 1e-5).all()
+
+
+def test_native_entry_points_actually_ran():
+    """Guard against a silent non-native path: after the tests above the call
+    counters of the C ABI must show the HIP kernels were the ones that ran."""
+    from veon_amd import _lib
+    g = load_golden('lss_small')
+    vt = _raw_from_golden(g)
+    before = dict(_lib.CALLS)
+    with torch.no_grad():
+        ds = vt.downsample_depth(dev(g['metric_depth']), 8)
+        th = vt.get_two_hot_depth(ds)
+        vt([dev(g['feat'])] + _inputs(g), th)
+    ran = {k for k, v in _lib.CALLS.items() if v > before.get(k, 0)}
+    for name in ('veon_downsample_depth', 'veon_two_hot_depth', 'veon_lss_prepare',
+                 'veon_bev_pool_row_table', 'veon_bev_pool_v2_fwd_maxpool'):
+        assert name in ran, (name, ran)

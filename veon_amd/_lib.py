@@ -79,7 +79,13 @@ def lib():
     return _lib
 
 
+# number of native calls per entry point (every call ends in check()); the GPU
+# tests assert on it so that a silent non-native path would be noticed
+CALLS = {}
+
+
 def check(status, what):
+    CALLS[what] = CALLS.get(what, 0) + 1
     if status != 0:
         msg = lib().veon_status_string(status).decode()
         raise VeonHipError('%s failed: %s (status %d)' % (what, msg, status))

@@ -8,7 +8,15 @@ device-agnostic behaviour, kept for host logic and CPU tests).
 """
 import torch
 
-_HIP = None  # set by veon_amd.depth_ops_hip
+_HIP = None  # veon_amd.depth_ops_hip registers itself here on import
+
+
+def _hip():
+    if _HIP is None:
+        from ._lib import VeonHipError
+        raise VeonHipError('veon_amd.depth_ops_hip is not loaded: ROCm tensors '
+                           'have no non-native path')
+    return _HIP
 
 
 def downsample_depth_torch(depths, downsample):
@@ -31,23 +39,23 @@ def two_hot_depth_torch(depths, D, lo, step, gamma=4, min_gap=-16.0):
 
 
 def downsample_depth(depths, downsample):
-    if depths.is_cuda and _HIP is not None:
-        return _HIP.downsample_depth(depths, downsample)
+    if depths.is_cuda:
+        return _hip().downsample_depth(depths, downsample)
     return downsample_depth_torch(depths, downsample)
 
 
 def two_hot_depth(depths, D, lo, step, gamma=4):
-    if depths.is_cuda and _HIP is not None:
-        return _HIP.two_hot_depth(depths, D, lo, step, gamma)
+    if depths.is_cuda:
+        return _hip().two_hot_depth(depths, D, lo, step, gamma)
     return two_hot_depth_torch(depths, D, lo, step, gamma)
 
 
 def two_hot_depth_fused(depths, downsample, D, lo, step, gamma=4):
     """downsample_depth + get_two_hot_depth in one pass on a ROCm device
     (AlignNetOcc3D.prepare_depth, align_net_occ3d.py:320-326)."""
-    if depths.is_cuda and _HIP is not None:
-        return _HIP.two_hot_depth(depths, D, lo, step, gamma,
-                                  fused_downsample=downsample)
+    if depths.is_cuda:
+        return _hip().two_hot_depth(depths, D, lo, step, gamma,
+                                    fused_downsample=downsample)
     return two_hot_depth_torch(downsample_depth_torch(depths, downsample), D,
                                lo, step, gamma)
 

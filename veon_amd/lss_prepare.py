@@ -11,7 +11,8 @@ Two implementations sit behind the same functions:
 * CPU tensors -> the same arithmetic in torch ops.  The reference's prepare is
   itself device-agnostic torch code, so this is the reference's own CPU
   behaviour, kept for host-side logic and CPU tests; it is NOT a fallback for
-  the device path (a ROCm tensor never reaches it).
+  the device path: a ROCm tensor always goes to the HIP kernels and raises if
+  they are unavailable (``_hip()``), it can never reach the torch ops.
 
 Both emit the canonical *stable* order (ascending ``ranks_depth`` inside an
 interval); the reference's unstable argsort leaves that order unspecified.
@@ -20,7 +21,16 @@ import torch
 
 from .ops.bev_pool_v2.bev_pool import mark_sorted
 
-_HIP_PREPARE = None  # set by veon_amd.lss_prepare_hip when the kernels exist
+_HIP_PREPARE = None  # veon_amd.lss_prepare_hip registers itself here on import
+
+
+def _hip():
+    """The device implementation; a ROCm tensor never takes any other path."""
+    if _HIP_PREPARE is None:
+        from ._lib import VeonHipError
+        raise VeonHipError('veon_amd.lss_prepare_hip is not loaded: ROCm tensors '
+                           'have no non-native path')
+    return _HIP_PREPARE
 
 
 def camera_matrices(sensor2ego, cam2imgs, post_rots):
@@ -59,8 +69,8 @@ def lidar_coor_from_matrices(frustum, post_rots_inv, post_trans, combine, trans,
                              bda):
     """Per-point half of get_lidar_coor (:144-155) given the camera matrices.
     Bit-identical to the reference's CPU result for identical matrices."""
-    if combine.is_cuda and _HIP_PREPARE is not None:
-        return _HIP_PREPARE.lidar_coor_from_matrices(
+    if combine.is_cuda:
+        return _hip().lidar_coor_from_matrices(
             frustum, post_rots_inv, post_trans, combine, trans, bda)
     return lidar_coor_from_matrices_torch(frustum, post_rots_inv, post_trans,
                                           combine, trans, bda)
@@ -105,9 +115,8 @@ def voxel_pooling_prepare_v2_torch(coor, lower, interval, gsize):
 
 
 def voxel_pooling_prepare_v2(coor, lower, interval, gsize):
-    if coor.is_cuda and _HIP_PREPARE is not None:
-        return _HIP_PREPARE.voxel_pooling_prepare_v2(coor, lower, interval,
-                                                     gsize)
+    if coor.is_cuda:
+        return _hip().voxel_pooling_prepare_v2(coor, lower, interval, gsize)
     return voxel_pooling_prepare_v2_torch(coor, lower, interval, gsize)
 
 
@@ -115,8 +124,8 @@ def prepare_from_matrices(frustum, post_rots_inv, post_trans, combine, trans,
                           bda, lower, interval, gsize):
     """get_lidar_coor's per-point half + voxel_pooling_prepare_v2 in one go
     (on a ROCm device the coordinates are never materialised)."""
-    if combine.is_cuda and _HIP_PREPARE is not None:
-        return _HIP_PREPARE.prepare_from_matrices(
+    if combine.is_cuda:
+        return _hip().prepare_from_matrices(
             frustum, post_rots_inv, post_trans, combine, trans, bda, lower,
             interval, gsize)
     coor = lidar_coor_from_matrices_torch(frustum, post_rots_inv, post_trans,
