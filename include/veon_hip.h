@@ -36,6 +36,11 @@ extern "C" {
 #define VEON_LAYOUT_BZYXC 0 /* (B,Z,Y,X,C): QuickCumsumCuda's `out`, bev_pool.py:27 */
 #define VEON_LAYOUT_BCZYX 1 /* (B,C,Z,Y,X): bev_pool_v2()'s return, bev_pool.py:91  */
 
+/* storage type of the feature rows for the *_ex entry points */
+#define VEON_FEAT_F32 0
+#define VEON_FEAT_F16 1  /* IEEE half */
+#define VEON_FEAT_BF16 2
+
 int veon_abi_version(void);
 const char *veon_status_string(int status);
 
@@ -134,6 +139,32 @@ int veon_bev_pool_v2_fwd_maxpool(int c, int n_intervals, int batch, int Z, int Y
                                  const int *interval_lengths,
                                  const int *row_first, float *out,
                                  void *stream);
+
+/*
+ * Half-precision feature rows.  QuickCumsumCuda.forward widens feat to fp32
+ * before the kernel (bev_pool.py:21 `feat.contiguous().float()`); the *_ex
+ * entry points read fp16 / bf16 rows (`feat_dtype` = VEON_FEAT_*) and widen in
+ * registers -- identical arithmetic (the widening is exact, the fmaf chain and
+ * the output stay fp32) at half the gather bytes and no fp32 copy of feat.
+ * With VEON_FEAT_F32 they are the functions above.
+ */
+int veon_bev_pool_v2_fwd_fused_ex(int c, int n_intervals, int batch,
+                                  int64_t voxels_per_batch, const float *depth,
+                                  const void *feat, int feat_dtype,
+                                  const int *ranks_depth, const int *ranks_feat,
+                                  const int *ranks_bev,
+                                  const int *interval_starts,
+                                  const int *interval_lengths, const int *plan,
+                                  float *out, int out_layout, void *stream);
+int veon_bev_pool_v2_fwd_maxpool_ex(int c, int n_intervals, int batch, int Z,
+                                    int Y, int X, int dz, int dy, int dx,
+                                    const float *depth, const void *feat,
+                                    int feat_dtype, const int *ranks_depth,
+                                    const int *ranks_feat, const int *ranks_bev,
+                                    const int *interval_starts,
+                                    const int *interval_lengths,
+                                    const int *row_first, float *out,
+                                    void *stream);
 
 /*
  * The per-camera 3x3 algebra of get_lidar_coor

@@ -356,3 +356,73 @@ def test_random_structures_backward_bit_exact(seed):
     out.backward(dev(og.transpose(0, 4, 1, 2, 3)))
     assert np.array_equal(d.grad.cpu().numpy(), want_dg)
     assert np.array_equal(f.grad.cpu().numpy(), want_fg)
+
+
+# ---------------------------------------------------------------------------
+# half-precision feature rows (veon_bev_pool_v2_fwd_fused_ex / _maxpool_ex)
+# ---------------------------------------------------------------------------
+def _half_feat(feat, dtype):
+    """(device half tensor, the same values widened to fp32 on the host): the
+    reference's `feat.float()` (bev_pool.py:21) is exact, so the oracle on the
+    widened rows is the bit-exact expectation."""
+    h = torch.from_numpy(feat).to(dtype)
+    return h.to(DEV), h.float().numpy()
+
+
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize('seed', range(8))
+def test_half_feat_random_structures_bit_exact(seed, dtype):
+    rng = np.random.default_rng(3000 + seed)
+    depth, feat, ranks, shape = _random_case(rng)
+    feat_h, feat_w = _half_feat(feat, dtype)
+    want = _oracle_out(depth, feat_w, ranks, shape)
+    rb, rd, rf, st, ln = (dev(a) for a in ranks)
+    B, Z, Y, X, C = shape
+    before = dict(_lib.CALLS)
+    for layout, expect in ((_lib.LAYOUT_BZYXC, want),
+                           (_lib.LAYOUT_BCZYX, want.transpose(0, 4, 1, 2, 3))):
+        out = bp._fused_forward(dev(depth), feat_h, rd, rf, rb, st, ln, shape, layout)
+        assert out.dtype == torch.float32
+        assert np.array_equal(out.cpu().numpy(), expect)
+    assert _lib.CALLS['veon_bev_pool_v2_fwd_fused_ex'] - \
+        before.get('veon_bev_pool_v2_fwd_fused_ex', 0) == 2
+    # through the op: inference keeps the half rows, result still fp32
+    with torch.no_grad():
+        got = bev_pool_v2(dev(depth), feat_h, rd, rf, rb, shape, st, ln)
+    assert got.dtype == torch.float32
+    assert np.array_equal(got.cpu().numpy(), want.transpose(0, 4, 1, 2, 3))
+    ds = tuple(2 if n % 2 == 0 else 1 for n in (Z, Y, X))
+    mp = bp.bev_pool_v2_maxpool(dev(depth), feat_h, rd, rf, rb, shape, st, ln, ds)
+    assert np.array_equal(mp.cpu().numpy(),
+                          c_oracle.maxpool3d(want.transpose(0, 4, 1, 2, 3), ds))
+
+
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
+def test_half_feat_veon_shape_bit_exact(dtype):
+    """SV (6 cams 512x1408, D=88, C=256): fused kernel and fused max-pool on
+    half rows equal the oracle on the widened rows."""
+    depth, feat, ranks, shape = _synthetic_case(synthetic.GRID_VEON, (512, 1408), 6, 256)
+    feat_h, feat_w = _half_feat(feat, dtype)
+    want = _oracle_out(depth, feat_w, ranks, shape).transpose(0, 4, 1, 2, 3)
+    rb, rd, rf, st, ln = (dev(a) for a in ranks)
+    bp.mark_sorted(st, int(ranks[0][0]), int(ranks[0][-1]))
+    with torch.no_grad():
+        got = bev_pool_v2(dev(depth), feat_h, rd, rf, rb, shape, st, ln)
+    assert np.array_equal(got.cpu().numpy(), want)
+    mp = bp.bev_pool_v2_maxpool(dev(depth), feat_h, rd, rf, rb, shape, st, ln, (2, 2, 2))
+    assert np.array_equal(mp.cpu().numpy(), c_oracle.maxpool3d(want, (2, 2, 2)))
+
+
+def test_half_feat_with_grad_takes_fp32_autograd_path():
+    """Training: the reference widens and differentiates in fp32
+    (bev_pool.py:21, 43-83); half rows that need a gradient do the same."""
+    depth, feat, ranks, shape = _case_from_golden('lss_small')
+    rb, rd, rf, st, ln = (dev(a) for a in ranks)
+    f = torch.from_numpy(feat).to(torch.float16).to(DEV).requires_grad_(True)
+    d = dev(depth).requires_grad_(True)
+    out = bev_pool_v2(d, f, rd, rf, rb, shape, st, ln)
+    out.sum().backward()
+    assert f.grad is not None and f.grad.dtype == torch.float16
+    assert d.grad is not None and torch.isfinite(d.grad).all()
+    want = _oracle_out(depth, f.detach().float().cpu().numpy(), ranks, shape)
+    assert np.array_equal(out.detach().cpu().numpy(), want.transpose(0, 4, 1, 2, 3))

@@ -377,5 +377,5 @@ def test_native_entry_points_actually_ran():
         vt([dev(g['feat'])] + _inputs(g), th)
     ran = {k for k, v in _lib.CALLS.items() if v > before.get(k, 0)}
     for name in ('veon_downsample_depth', 'veon_two_hot_depth', 'veon_lss_prepare',
-                 'veon_bev_pool_row_table', 'veon_bev_pool_v2_fwd_maxpool'):
+                 'veon_bev_pool_row_table', 'veon_bev_pool_v2_fwd_maxpool_ex'):
         assert name in ran, (name, ran)

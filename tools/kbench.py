@@ -143,6 +143,23 @@ def main():
     def zero_fill():
         out.zero_()
 
+    feat_h = feat.half()
+    feat_b = feat.bfloat16()
+
+    def product_cf_f16():
+        return bp._fused_forward(depth, feat_h, rd, rf, rb, st, ln, shape, _lib.LAYOUT_BCZYX)
+
+    def product_cf_bf16():
+        return bp._fused_forward(depth, feat_b, rd, rf, rb, st, ln, shape, _lib.LAYOUT_BCZYX)
+
+    bp.build_row_table(rb, st, 1, vpb, X)
+
+    def product_maxpool():
+        return bp.bev_pool_v2_maxpool(depth, feat, rd, rf, rb, shape, st, ln, (2, 2, 2))
+
+    def product_maxpool_f16():
+        return bp.bev_pool_v2_maxpool(depth, feat_h, rd, rf, rb, shape, st, ln, (2, 2, 2))
+
     def var(v, cs):
         def f():
             r = V.poolvar_run(v, C, cs, st.numel(), 1, ctypes.c_int64(vpb), _lib.ptr(depth),
@@ -197,7 +214,9 @@ def main():
         return
     cs_opts = [C] if C <= 128 else [64, 128]
     cases = [('zero_fill(torch)', zero_fill), ('product_cf_percall_plan', product_cf_search),
-             ('product_cl', product_cl), ('product_cf_cached_plan', product_cf_table)]
+             ('product_cl', product_cl), ('product_cf_cached_plan', product_cf_table),
+             ('product_cf_f16', product_cf_f16), ('product_cf_bf16', product_cf_bf16),
+             ('product_maxpool', product_maxpool), ('product_maxpool_f16', product_maxpool_f16)]
     queue = torch.zeros(4, dtype=torch.int32, device=dev)
     def var5(v, cs, wpc):
         f = var(v, cs)
@@ -205,8 +224,7 @@ def main():
             V.poolvar_set_queue(ctypes.c_void_p(0), wpc)
             f()
         return g
-    cases.append(('var43 cs=%d' % cs_opts[0], var(43, cs_opts[0])))
-    for v in [43, 110, 120]:
+    for v in []:
         for cs in cs_opts:
             cases.append(('var%d cs=%d' % (v, cs), var(v, cs)))
     for v in []:

@@ -24,7 +24,7 @@ constexpr int kWave = 64;
 
 struct PoolArgs {
   const float* __restrict__ depth;
-  const float* __restrict__ feat;
+  const void* __restrict__ feat;  // float / fp16 / bf16 rows, see FeatF32...
   const int* __restrict__ ranks_depth;
   const int* __restrict__ ranks_feat;
   const int* __restrict__ ranks_bev;
@@ -47,6 +47,14 @@ struct Vec<4> {
   using T = float4;
 };
 
+struct float8 {
+  float4 lo, hi;
+};
+template <>
+struct Vec<8> {
+  using T = float8;
+};
+
 template <int VEC>
 __device__ __forceinline__ void vfma(typename Vec<VEC>::T& acc,
                                      const typename Vec<VEC>::T& f, float d);
@@ -67,6 +75,12 @@ __device__ __forceinline__ void vfma<4>(float4& acc, const float4& f, float d) {
   acc.w = fmaf(f.w, d, acc.w);
 }
 
+template <>
+__device__ __forceinline__ void vfma<8>(float8& acc, const float8& f, float d) {
+  vfma<4>(acc.lo, f.lo, d);
+  vfma<4>(acc.hi, f.hi, d);
+}
+
 template <int VEC>
 __device__ __forceinline__ typename Vec<VEC>::T vzero();
 template <>
@@ -82,10 +96,70 @@ __device__ __forceinline__ float4 vzero<4>() {
   return make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
+template <>
+__device__ __forceinline__ float8 vzero<8>() {
+  return float8{make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+}
+
+// Feature storage types.  The reference casts feat to fp32 before the kernel
+// (bev_pool.py:21); reading half-precision rows and widening in registers is
+// the same arithmetic (the widening is exact) at half the gather bytes.
+struct FeatF32 {
+  using S = float;
+};
+struct FeatF16 {
+  using S = _Float16;
+};
+struct FeatBF16 {
+  using S = unsigned short;
+};
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ float bf_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf_hi(unsigned u) {
+  return __uint_as_float(u & 0xffff0000u);
+}
+
+// VEC consecutive channels of one feat row starting at element `e`
+template <typename FT, int VEC>
+__device__ __forceinline__ typename Vec<VEC>::T load_feat(const void* feat,
+                                                          int64_t e) {
+  using V = typename Vec<VEC>::T;
+  if constexpr (__is_same(FT, FeatF32)) {
+    static_assert(VEC <= 4, "fp32 rows are read 16 bytes at a time");
+    return *reinterpret_cast<const V*>(static_cast<const float*>(feat) + e);
+  } else if constexpr (__is_same(FT, FeatF16)) {
+    const _Float16* p = static_cast<const _Float16*>(feat) + e;
+    if constexpr (VEC == 1) {
+      return (float)p[0];
+    } else if constexpr (VEC == 4) {
+      const half4_t h = *reinterpret_cast<const half4_t*>(p);
+      return make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+    } else {
+      const half8_t h = *reinterpret_cast<const half8_t*>(p);
+      return float8{make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]),
+                    make_float4((float)h[4], (float)h[5], (float)h[6], (float)h[7])};
+    }
+  } else {
+    const unsigned short* p = static_cast<const unsigned short*>(feat) + e;
+    if constexpr (VEC == 1) {
+      return __uint_as_float((unsigned)p[0] << 16);
+    } else if constexpr (VEC == 4) {
+      const uint2 u = *reinterpret_cast<const uint2*>(p);
+      return make_float4(bf_lo(u.x), bf_hi(u.x), bf_lo(u.y), bf_hi(u.y));
+    } else {
+      const uint4 u = *reinterpret_cast<const uint4*>(p);
+      return float8{make_float4(bf_lo(u.x), bf_hi(u.x), bf_lo(u.y), bf_hi(u.y)),
+                    make_float4(bf_lo(u.z), bf_hi(u.z), bf_lo(u.w), bf_hi(u.w))};
+    }
+  }
+}
+
 // Serial pooled sum of one interval for VEC consecutive channels starting at
 // channel `ch`.  The index / depth loads are identical across the lanes that
 // share an interval (hardware broadcast); the feat loads are channel-contiguous.
-template <int VEC>
+template <int VEC, typename FT = FeatF32>
 __device__ __forceinline__ typename Vec<VEC>::T interval_sum(
     const PoolArgs& a, int c, int start, int len, int ch) {
   using V = typename Vec<VEC>::T;
@@ -105,7 +179,7 @@ __device__ __forceinline__ typename Vec<VEC>::T interval_sum(
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       d[k] = a.depth[rd[k]];
-      f[k] = *reinterpret_cast<const V*>(a.feat + (int64_t)rf[k] * c + ch);
+      f[k] = load_feat<FT, VEC>(a.feat, (int64_t)rf[k] * c + ch);
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) vfma<VEC>(acc, f[k], d[k]);
@@ -114,7 +188,7 @@ __device__ __forceinline__ typename Vec<VEC>::T interval_sum(
     const int rd = a.ranks_depth[start + i];
     const int rf = a.ranks_feat[start + i];
     const float d = a.depth[rd];
-    const V f = *reinterpret_cast<const V*>(a.feat + (int64_t)rf * c + ch);
+    const V f = load_feat<FT, VEC>(a.feat, (int64_t)rf * c + ch);
     vfma<VEC>(acc, f, d);
   }
   return acc;
@@ -218,7 +292,7 @@ __device__ __forceinline__ unsigned long long wave_or(unsigned long long bit) {
 //     64*C-float region; lanes map to (voxel, VEC channels) in memory order, so
 //     every store instruction is 64 x VEC*4 contiguous bytes.  No LDS data.
 // ---------------------------------------------------------------------------
-template <int VEC>
+template <int VEC, typename FT>
 __global__ __launch_bounds__(kBlock) void k_pool_fused_cl(
     PoolArgs a, const int4* __restrict__ plan, int c, int cq, int64_t vpb,
     int64_t tiles_per_batch, float* __restrict__ out) {
@@ -246,8 +320,8 @@ __global__ __launch_bounds__(kBlock) void k_pool_fused_cl(
     VT acc = vzero<VEC>();
     if ((mask >> v) & 1ull) {
       const int ii = i0 + __popcll(mask & ((1ull << v) - 1ull));
-      acc = interval_sum<VEC>(a, c, a.interval_starts[ii],
-                              a.interval_lengths[ii], ch);
+      acc = interval_sum<VEC, FT>(a, c, a.interval_starts[ii],
+                                  a.interval_lengths[ii], ch);
     }
     reinterpret_cast<VT*>(obase)[item] = acc;
   }
@@ -270,13 +344,13 @@ __global__ __launch_bounds__(kBlock) void k_pool_fused_cl(
 // ---------------------------------------------------------------------------
 constexpr int kPmax = 1024;  // points staged per window (8 B each)
 
-template <int VEC, int CAP>
+template <int VEC, int CAP, typename FT>
 __global__ __launch_bounds__(kBlock) void k_pool_fused_cf(
     PoolArgs a, const int4* __restrict__ plan, int c, int cs, int64_t vpb,
     int64_t tiles_per_batch, float* __restrict__ out) {
   extern __shared__ float lds[];
   constexpr int LDC = CAP + 1;
-  constexpr int UNROLL = 8;
+  constexpr int UNROLL = 8;  // rows in flight per lane
   constexpr int SB = 5;  // LDS reads batched ahead of the stores
   constexpr int NW = kBlock / kWave;
   float* tile = lds;                                             // [cs][LDC]
@@ -341,7 +415,7 @@ __global__ __launch_bounds__(kBlock) void k_pool_fused_cf(
           // one interval longer than the window: straight from global memory
           for (int q = tid; q < nq; q += kBlock) {
             const VT acc =
-                interval_sum<VEC>(a, c, p0 + st, len, c0 + q * VEC);
+                interval_sum<VEC, FT>(a, c, p0 + st, len, c0 + q * VEC);
             const float* ap = reinterpret_cast<const float*>(&acc);
 #pragma unroll
             for (int k = 0; k < VEC; ++k)
@@ -367,7 +441,7 @@ __global__ __launch_bounds__(kBlock) void k_pool_fused_cf(
         const int q = item - (j - j0) * nq;
         const int st = istart[j] - base;
         const int len = istart[j + 1] - istart[j];
-        const float* fcol = a.feat + c0 + q * VEC;
+        const int64_t fcol = c0 + q * VEC;
         VT acc = vzero<VEC>();
         int i = 0;
         for (; i + UNROLL <= len; i += UNROLL) {
@@ -375,8 +449,8 @@ __global__ __launch_bounds__(kBlock) void k_pool_fused_cf(
           float d[UNROLL];
 #pragma unroll
           for (int u = 0; u < UNROLL; ++u) {
-            f[u] = *reinterpret_cast<const VT*>(
-                fcol + (int64_t)s_rf[st + i + u] * c);
+            f[u] = load_feat<FT, VEC>(a.feat,
+                                      fcol + (int64_t)s_rf[st + i + u] * c);
             d[u] = a.depth[s_rd[st + i + u]];
           }
 #pragma unroll
@@ -384,7 +458,7 @@ __global__ __launch_bounds__(kBlock) void k_pool_fused_cf(
         }
         for (; i < len; ++i) {
           const VT f =
-              *reinterpret_cast<const VT*>(fcol + (int64_t)s_rf[st + i] * c);
+              load_feat<FT, VEC>(a.feat, fcol + (int64_t)s_rf[st + i] * c);
           vfma<VEC>(acc, f, a.depth[s_rd[st + i]]);
         }
         const float* ap = reinterpret_cast<const float*>(&acc);
@@ -449,7 +523,7 @@ __device__ __forceinline__ float key_float(int k) {
   return __int_as_float(k ^ ((k >> 31) & 0x7fffffff));
 }
 
-template <int VEC>
+template <int VEC, typename FT>
 __global__ __launch_bounds__(kBlock) void k_pool_maxpool_cf(
     PoolArgs a, const int* __restrict__ row_first, int c, int cs, int Z, int Y,
     int X, int dz, int dy, int dx, float* __restrict__ out) {
@@ -483,7 +557,7 @@ __global__ __launch_bounds__(kBlock) void k_pool_maxpool_cf(
         const int start = a.interval_starts[i0 + j];
         const int len = a.interval_lengths[i0 + j];
         const int xo = (int)((int64_t)a.ranks_bev[start] - rank0) / dx;
-        const VT acc = interval_sum<VEC>(a, c, start, len, c0 + q * VEC);
+        const VT acc = interval_sum<VEC, FT>(a, c, start, len, c0 + q * VEC);
         const float* ap = reinterpret_cast<const float*>(&acc);
 #pragma unroll
         for (int k = 0; k < VEC; ++k)
@@ -528,7 +602,8 @@ __global__ __launch_bounds__(kBwdBlock) void k_pool_bwd(
   using VT = typename Vec<VEC>::T;
   for (int i = threadIdx.x; i < len; i += kBwdBlock) {
     const float* og = out_grad + (int64_t)a.ranks_bev[start + i] * c;
-    const float* ft = a.feat + (int64_t)a.ranks_feat[start + i] * c;
+    const float* ft =
+        static_cast<const float*>(a.feat) + (int64_t)a.ranks_feat[start + i] * c;
     float s = 0.f;
     for (int cc = 0; cc < c; cc += VEC) {
       const VT o = *reinterpret_cast<const VT*>(og + cc);
@@ -696,18 +771,21 @@ int veon_bev_pool_row_table(int n_intervals, int n_points, int batch,
   return launch_status();
 }
 
-int veon_bev_pool_v2_fwd_maxpool(int c, int n_intervals, int batch, int Z, int Y,
-                                 int X, int dz, int dy, int dx,
-                                 const float* depth, const float* feat,
-                                 const int* ranks_depth, const int* ranks_feat,
-                                 const int* ranks_bev,
-                                 const int* interval_starts,
-                                 const int* interval_lengths,
-                                 const int* row_first, float* out,
-                                 void* stream) {
+int veon_bev_pool_v2_fwd_maxpool_ex(int c, int n_intervals, int batch, int Z,
+                                    int Y, int X, int dz, int dy, int dx,
+                                    const float* depth, const void* feat,
+                                    int feat_dtype, const int* ranks_depth,
+                                    const int* ranks_feat, const int* ranks_bev,
+                                    const int* interval_starts,
+                                    const int* interval_lengths,
+                                    const int* row_first, float* out,
+                                    void* stream) {
   if (c <= 0 || n_intervals < 0 || batch <= 0 || Z <= 0 || Y <= 0 || X <= 0 ||
       dz <= 0 || dy <= 0 || dx <= 0 || Z % dz || Y % dy || X % dx || !out ||
       !row_first)
+    return VEON_ERR_BAD_ARG;
+  if (feat_dtype != VEON_FEAT_F32 && feat_dtype != VEON_FEAT_F16 &&
+      feat_dtype != VEON_FEAT_BF16)
     return VEON_ERR_BAD_ARG;
   if (n_intervals > 0 &&
       (!depth || !feat || !ranks_depth || !ranks_feat || !ranks_bev ||
@@ -719,34 +797,70 @@ int veon_bev_pool_v2_fwd_maxpool(int c, int n_intervals, int batch, int Z, int Y
   const int Xo = X / dx;
   // channel slab so that the [cs][Xo] key tile stays <= 16 KB (occupancy first)
   int cs = c;
-  while ((int64_t)cs * Xo * 4 > 16384 && cs > 4) cs = (cs / 2 + 3) / 4 * 4;
+  while ((int64_t)cs * Xo * 4 > 16384 && cs > 8) cs = (cs / 2 + 7) / 8 * 8;
   const int slabs = (c + cs - 1) / cs;
-  const bool v4 = (c % 4 == 0) && (cs % 4 == 0) && aligned16(feat);
   const size_t lds = ((size_t)cs * Xo + Xo) * sizeof(int);
   const int64_t orows = (int64_t)batch * (Z / dz) * (Y / dy);
   if (orows > 0x7fffffffLL) return VEON_ERR_BAD_ARG;
   const dim3 grid((unsigned)orows, (unsigned)slabs);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (v4)
-    hipLaunchKernelGGL(k_pool_maxpool_cf<4>, grid, dim3(kBlock), lds, s, a,
-                       row_first, c, cs, Z, Y, X, dz, dy, dx, out);
-  else
-    hipLaunchKernelGGL(k_pool_maxpool_cf<1>, grid, dim3(kBlock), lds, s, a,
-                       row_first, c, cs, Z, Y, X, dz, dy, dx, out);
+#define VEON_LAUNCH_MP(VEC, FT)                                               \
+  hipLaunchKernelGGL((k_pool_maxpool_cf<VEC, FT>), grid, dim3(kBlock), lds, s, \
+                     a, row_first, c, cs, Z, Y, X, dz, dy, dx, out)
+  if (feat_dtype == VEON_FEAT_F32) {
+    if ((c % 4 == 0) && (cs % 4 == 0) && aligned16(feat))
+      VEON_LAUNCH_MP(4, FeatF32);
+    else
+      VEON_LAUNCH_MP(1, FeatF32);
+  } else {
+    // 16-byte gathers (8 channels per lane) pay at VEON's C = 256; at C = 80
+    // they leave too few lanes busy and 8-byte gathers are faster (measured)
+    const bool v4 = (c % 4 == 0) && (cs % 4 == 0) && aligned16(feat);
+    const bool v8 = v4 && (c % 8 == 0) && (cs % 8 == 0) && c >= 128;
+    if (feat_dtype == VEON_FEAT_F16) {
+      if (v8) VEON_LAUNCH_MP(8, FeatF16);
+      else if (v4) VEON_LAUNCH_MP(4, FeatF16);
+      else VEON_LAUNCH_MP(1, FeatF16);
+    } else {
+      if (v8) VEON_LAUNCH_MP(8, FeatBF16);
+      else if (v4) VEON_LAUNCH_MP(4, FeatBF16);
+      else VEON_LAUNCH_MP(1, FeatBF16);
+    }
+  }
+#undef VEON_LAUNCH_MP
   return launch_status();
 }
 
-int veon_bev_pool_v2_fwd_fused(int c, int n_intervals, int batch,
-                               int64_t voxels_per_batch, const float* depth,
-                               const float* feat, const int* ranks_depth,
-                               const int* ranks_feat, const int* ranks_bev,
-                               const int* interval_starts,
-                               const int* interval_lengths, const int* plan,
-                               float* out, int out_layout, void* stream) {
+int veon_bev_pool_v2_fwd_maxpool(int c, int n_intervals, int batch, int Z, int Y,
+                                 int X, int dz, int dy, int dx,
+                                 const float* depth, const float* feat,
+                                 const int* ranks_depth, const int* ranks_feat,
+                                 const int* ranks_bev,
+                                 const int* interval_starts,
+                                 const int* interval_lengths,
+                                 const int* row_first, float* out,
+                                 void* stream) {
+  return veon_bev_pool_v2_fwd_maxpool_ex(
+      c, n_intervals, batch, Z, Y, X, dz, dy, dx, depth, feat, VEON_FEAT_F32,
+      ranks_depth, ranks_feat, ranks_bev, interval_starts, interval_lengths,
+      row_first, out, stream);
+}
+
+int veon_bev_pool_v2_fwd_fused_ex(int c, int n_intervals, int batch,
+                                  int64_t voxels_per_batch, const float* depth,
+                                  const void* feat, int feat_dtype,
+                                  const int* ranks_depth, const int* ranks_feat,
+                                  const int* ranks_bev,
+                                  const int* interval_starts,
+                                  const int* interval_lengths, const int* plan,
+                                  float* out, int out_layout, void* stream) {
   if (c <= 0 || n_intervals < 0 || batch <= 0 || voxels_per_batch <= 0 ||
       !out || !plan)
     return VEON_ERR_BAD_ARG;
   if (out_layout != VEON_LAYOUT_BZYXC && out_layout != VEON_LAYOUT_BCZYX)
+    return VEON_ERR_BAD_ARG;
+  if (feat_dtype != VEON_FEAT_F32 && feat_dtype != VEON_FEAT_F16 &&
+      feat_dtype != VEON_FEAT_BF16)
     return VEON_ERR_BAD_ARG;
   if (n_intervals > 0 &&
       (!depth || !feat || !ranks_depth || !ranks_feat || !ranks_bev ||
@@ -762,16 +876,21 @@ int veon_bev_pool_v2_fwd_fused(int c, int n_intervals, int batch,
   const int64_t n_tiles = tiles_per_batch * batch;
   if (n_tiles > 0x3fffffffLL) return VEON_ERR_BAD_ARG;
   const int4* plan4 = reinterpret_cast<const int4*>(plan);
-  const bool v4 = (c % 4 == 0) && aligned16(feat);
   if (out_layout == VEON_LAYOUT_BZYXC) {
-    if (v4 && aligned16(out))
-      hipLaunchKernelGGL(k_pool_fused_cl<4>, dim3((unsigned)n_tiles),
-                         dim3(kBlock), 0, s, a, plan4, c, c / 4,
-                         voxels_per_batch, tiles_per_batch, out);
-    else
-      hipLaunchKernelGGL(k_pool_fused_cl<1>, dim3((unsigned)n_tiles),
-                         dim3(kBlock), 0, s, a, plan4, c, c, voxels_per_batch,
-                         tiles_per_batch, out);
+    // lanes = (voxel, 4 channels) so that stores stay 16 bytes per lane
+    const bool v4 = (c % 4 == 0) && aligned16(feat) && aligned16(out);
+#define VEON_LAUNCH_CL(VEC, FT)                                                \
+  hipLaunchKernelGGL((k_pool_fused_cl<VEC, FT>), dim3((unsigned)n_tiles),      \
+                     dim3(kBlock), 0, s, a, plan4, c, c / VEC,                 \
+                     voxels_per_batch, tiles_per_batch, out)
+    if (feat_dtype == VEON_FEAT_F32) {
+      if (v4) VEON_LAUNCH_CL(4, FeatF32); else VEON_LAUNCH_CL(1, FeatF32);
+    } else if (feat_dtype == VEON_FEAT_F16) {
+      if (v4) VEON_LAUNCH_CL(4, FeatF16); else VEON_LAUNCH_CL(1, FeatF16);
+    } else {
+      if (v4) VEON_LAUNCH_CL(4, FeatBF16); else VEON_LAUNCH_CL(1, FeatBF16);
+    }
+#undef VEON_LAUNCH_CL
     return launch_status();
   }
   // channels-first: channel slab and LDS tile width by problem shape
@@ -782,16 +901,40 @@ int veon_bev_pool_v2_fwd_fused(int c, int n_intervals, int batch,
   const size_t lds = (size_t)cs * (cap + 1) * sizeof(float) +
                      (size_t)(2 * kTileV + 2 + 2 * kPmax) * sizeof(int);
   const dim3 grid((unsigned)n_tiles, (unsigned)slabs);
-#define VEON_LAUNCH_CF(VEC, CAP)                                              \
-  hipLaunchKernelGGL((k_pool_fused_cf<VEC, CAP>), grid, dim3(kBlock), lds, s, \
-                     a, plan4, c, cs, voxels_per_batch, tiles_per_batch, out)
-  if (v4) {
-    if (dense) VEON_LAUNCH_CF(4, 64); else VEON_LAUNCH_CF(4, 32);
+#define VEON_LAUNCH_CF(VEC, CAP, FT)                                          \
+  hipLaunchKernelGGL((k_pool_fused_cf<VEC, CAP, FT>), grid, dim3(kBlock), lds, \
+                     s, a, plan4, c, cs, voxels_per_batch, tiles_per_batch, out)
+#define VEON_LAUNCH_CF2(VEC, FT) \
+  do { if (dense) VEON_LAUNCH_CF(VEC, 64, FT); else VEON_LAUNCH_CF(VEC, 32, FT); } while (0)
+  if (feat_dtype == VEON_FEAT_F32) {
+    if ((c % 4 == 0) && aligned16(feat)) VEON_LAUNCH_CF2(4, FeatF32);
+    else VEON_LAUNCH_CF2(1, FeatF32);
   } else {
-    if (dense) VEON_LAUNCH_CF(1, 64); else VEON_LAUNCH_CF(1, 32);
+    // 4 channels (8 bytes) per lane: the kernel is latency-, not byte-bound,
+    // and 8 channels per lane halve the lanes in flight (measured slower)
+    const bool v4 = (c % 4 == 0) && (cs % 4 == 0) && aligned16(feat);
+    if (feat_dtype == VEON_FEAT_F16) {
+      if (v4) VEON_LAUNCH_CF2(4, FeatF16); else VEON_LAUNCH_CF2(1, FeatF16);
+    } else {
+      if (v4) VEON_LAUNCH_CF2(4, FeatBF16); else VEON_LAUNCH_CF2(1, FeatBF16);
+    }
   }
+#undef VEON_LAUNCH_CF2
 #undef VEON_LAUNCH_CF
   return launch_status();
+}
+
+int veon_bev_pool_v2_fwd_fused(int c, int n_intervals, int batch,
+                               int64_t voxels_per_batch, const float* depth,
+                               const float* feat, const int* ranks_depth,
+                               const int* ranks_feat, const int* ranks_bev,
+                               const int* interval_starts,
+                               const int* interval_lengths, const int* plan,
+                               float* out, int out_layout, void* stream) {
+  return veon_bev_pool_v2_fwd_fused_ex(
+      c, n_intervals, batch, voxels_per_batch, depth, feat, VEON_FEAT_F32,
+      ranks_depth, ranks_feat, ranks_bev, interval_starts, interval_lengths,
+      plan, out, out_layout, stream);
 }
 
 }  // extern "C"

@@ -21,6 +21,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "../../include/veon_hip.h"
 
 namespace {
@@ -89,15 +91,17 @@ __global__ __launch_bounds__(256) void k_layernorm(
 }
 
 // ----------------------------------------------------------------------- GEMM
-// 128x128 output tile, BK = 64, 256 threads = 4 waves in 2(M) x 2(N), each wave
-// 64 tokens x 64 features = 4x4 MFMA tiles.  Operands go global -> LDS directly
+// (32*MT) x 128 output tile, BK = 64, 256 threads = 4 waves in 2(M) x 2(N), each
+// wave (16*MT) tokens x 64 features = MT x 4 MFMA tiles.  MT in {2,4} (tile
+// heights 64/128) is picked per shape by the launcher.  Operands go global -> LDS directly
 // (global_load_lds_dwordx4: no VGPR staging, 1 KiB per wave instruction) into a
 // double-buffered image whose 16-byte chunks are XOR-swizzled by the row
 // (chunk ^= row & 7): the DMA writes LDS linearly, so the permutation is applied
 // to the per-lane SOURCE address, and again on the fragment reads, which makes
 // every ds_read_b128 of the 16x16x32 operand maps bank-conflict free.
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int TILE_ELEMS = BM * BK;  // per operand per buffer (16 KiB)
+constexpr int BN = 128, BK = 64;
+constexpr int W_ELEMS = BN * BK;  // weight slab per buffer (16 KiB)
+constexpr int kNumCU = 256;       // MI355X
 
 enum { EPI_BF16 = 0, EPI_GELU = 1, EPI_QUICKGELU = 2, EPI_RESID = 3 };
 
@@ -123,58 +127,72 @@ __device__ __forceinline__ float quick_gelu(float x) {
 typedef const void __attribute__((address_space(1))) * gptr_t;
 typedef void __attribute__((address_space(3))) * lptr_t;
 
-template <int EPI>
+template <int EPI, int MT>
 __global__ __launch_bounds__(256) void k_gemm_bf16(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
     const float* __restrict__ bias, const float* __restrict__ gamma,
     float* __restrict__ resid, bf16_t* __restrict__ out, int M, int N, int K) {
   // one array for all staging (a second __shared__ object beside a DMA target
   // can make hipcc drain vmcnt before every ds_read: guide section 5 item 4a)
-  __shared__ __attribute__((aligned(16))) bf16_t smem[4 * TILE_ELEMS];
+  constexpr int BM = 32 * MT;           // tile height
+  constexpr int A_ELEMS = BM * BK;      // activation slab per buffer
+  constexpr int BUF_ELEMS = A_ELEMS + W_ELEMS;
+  extern __shared__ __attribute__((aligned(16))) bf16_t smem[];  // [2][A|W]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   const int fr = lane & 15, fg = lane >> 4;
 
-  // DMA map: wave instruction j (0..3) of wave w fills LDS chunks
-  // [(w*4 + j)*64, +64) of a tile = rows (w*4 + j)*8 .. +8; lane l lands in row
-  // r = base + l/8, physical chunk l%8, so it must fetch logical chunk
-  // (l%8) ^ (r&7).  Rows beyond M / N are clamped (their outputs are dropped).
-  const bf16_t* srcA[4];
+  // DMA map: a wave instruction fills 64 LDS chunks = 8 rows of a slab; wave w
+  // issues pieces w*MT .. +MT of the activation slab (BM/8 = 4*MT pieces) and
+  // w*4 .. +4 of the weight slab; lane l lands in row r = 8*piece + l/8, physical
+  // chunk l%8, so it must fetch logical chunk (l%8) ^ (r&7).  Rows beyond M / N
+  // are clamped (their outputs are dropped).
+  const bf16_t* srcA[MT];
   const bf16_t* srcW[4];
+#pragma unroll
+  for (int j = 0; j < MT; ++j) {
+    const int r = (wave * MT + j) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ (r & 7);
+    const int gm = m0 + r < M ? m0 + r : M - 1;
+    srcA[j] = A + (int64_t)gm * K + c * 8;
+  }
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int r = (wave * 4 + j) * 8 + (lane >> 3);
     const int c = (lane & 7) ^ (r & 7);
-    const int gm = m0 + r < M ? m0 + r : M - 1;
     const int gn = n0 + r < N ? n0 + r : N - 1;
-    srcA[j] = A + (int64_t)gm * K + c * 8;
     srcW[j] = W + (int64_t)gn * K + c * 8;
   }
   auto dma = [&](int buf, int k0) {
-    bf16_t* dA = smem + buf * 2 * TILE_ELEMS;
-    bf16_t* dW = dA + TILE_ELEMS;
+    bf16_t* dA = smem + buf * BUF_ELEMS;
+    bf16_t* dW = dA + A_ELEMS;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int slot = (wave * 4 + j) * 512;  // bf16 elements: 64 lanes x 8
-      __builtin_amdgcn_global_load_lds((gptr_t)(srcA[j] + k0), (lptr_t)(dA + slot), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gptr_t)(srcW[j] + k0), (lptr_t)(dW + slot), 16, 0, 0);
-    }
+    for (int j = 0; j < MT; ++j)
+      __builtin_amdgcn_global_load_lds((gptr_t)(srcA[j] + k0),
+                                       (lptr_t)(dA + (wave * MT + j) * 512), 16, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      __builtin_amdgcn_global_load_lds((gptr_t)(srcW[j] + k0),
+                                       (lptr_t)(dW + (wave * 4 + j) * 512), 16, 0, 0);
   };
 
-  f32x4 acc[4][4];  // [token tile][feature tile]
+  f32x4 acc[MT][4];  // [token tile][feature tile]
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // fragment read offsets (bf16 elements) for ks = 0; ks = 1 flips chunk bit 2
-  int offA[4], offW[4];
+  int offA[MT], offW[4];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int ra = wm * (16 * MT) + i * 16 + fr;
+    offA[i] = ra * BK + ((fg ^ (ra & 7)) * 8);
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int ra = wm * 64 + i * 16 + fr;
     const int rw = wn * 64 + i * 16 + fr;
-    offA[i] = ra * BK + ((fg ^ (ra & 7)) * 8);
     offW[i] = rw * BK + ((fg ^ (rw & 7)) * 8);
   }
 
@@ -184,19 +202,19 @@ __global__ __launch_bounds__(256) void k_gemm_bf16(
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
     if (kt + 1 < nk) dma(buf ^ 1, (kt + 1) * BK);
-    const bf16_t* tA = smem + buf * 2 * TILE_ELEMS;
-    const bf16_t* tW = tA + TILE_ELEMS;
+    const bf16_t* tA = smem + buf * BUF_ELEMS;
+    const bf16_t* tW = tA + A_ELEMS;
 #pragma unroll
     for (int ks = 0; ks < BK / 32; ++ks) {
-      bf16x8 fa[4], fw[4];
+      bf16x8 fa[MT], fw[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < MT; ++i)
         fa[i] = *reinterpret_cast<const bf16x8*>(tA + (offA[i] ^ (ks * 32)));
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         fw[j] = *reinterpret_cast<const bf16x8*>(tW + (offW[j] ^ (ks * 32)));
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           // weight rows as MFMA "A", token rows as "B":
@@ -209,8 +227,8 @@ __global__ __launch_bounds__(256) void k_gemm_bf16(
 
   // epilogue: lane owns 4 consecutive features of one token per tile
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + wm * 64 + i * 16 + fr;
+  for (int i = 0; i < MT; ++i) {
+    const int m = m0 + wm * (16 * MT) + i * 16 + fr;
     if (m >= M) continue;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -249,24 +267,35 @@ __global__ __launch_bounds__(256) void k_gemm_bf16(
 // qkv: [B, T, 3, H, 64] bf16 (the packed output of the qkv projection, q already
 // scaled by head_dim^-0.5 through the weights).  out: [B, T, H*64] bf16.
 // Optional additive bias [B or 1][H or 1][T][T] fp32 (CLIP tail; strides given).
-// Workgroup = 256 threads = 4 waves, 32 queries per wave; keys/values streamed
-// in tiles of 64 through LDS, both row-major: K fragments are 16-B row reads,
-// V^T fragments come from the hardware transposing read ds_read_b64_tr_b16.
-// The next tile's global loads are in flight while the current one is consumed.
+// Workgroup = 256 threads = 4 waves, 32 queries per wave.  K/V tiles of 64 keys
+// go global -> LDS by DMA (global_load_lds_dwordx4, no VGPR staging) into a
+// double buffer whose 16-byte chunks are XOR-swizzled by the row exactly as in
+// the GEMM; one barrier per tile.  S^T = K.Q^T so the softmax statistics of a
+// query are lane-local; K fragments are 16-B LDS reads, V^T fragments come from
+// the hardware transposing read ds_read_b64_tr_b16.  With head_dim 64 the
+// kernel is VALU-bound (32 exp2 + ~100 other VALU ops against 32 MFMAs per wave
+// and tile), so the loop body is kept lean: bias and tail masking are compiled
+// out of the common path, the accumulator rescale is skipped when no running
+// maximum moved, exp2 takes its scale by one FMA.
 constexpr int HD = 64;        // head dim
 constexpr int QT = 2;         // 16-query tiles per wave
 constexpr int AQ = 16 * QT;   // queries per wave
 constexpr int AK = 64;        // keys per LDS tile
-constexpr int LDD = HD + 8;   // LDS row pitch (bf16): 144 B
+constexpr int KV_ELEMS = AK * HD;  // one operand tile (8 KiB)
 
-typedef short __attribute__((address_space(3))) lds_short;
 typedef bf16x4 __attribute__((address_space(3))) lds_bf16x4;
+typedef __bf16 __attribute__((ext_vector_type(2))) bf16pair;
+typedef float __attribute__((ext_vector_type(2))) f32x2;
 
-__global__ __launch_bounds__(256) void k_attention(
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, bf16pair));
+}
+
+template <bool HAS_BIAS>
+__global__ __launch_bounds__(256, 2) void k_attention(
     const bf16_t* __restrict__ qkv, const float* __restrict__ bias,
     int64_t bias_sb, int64_t bias_sh, bf16_t* __restrict__ out, int T, int H) {
-  __shared__ __attribute__((aligned(16))) bf16_t sK[AK * LDD];
-  __shared__ __attribute__((aligned(16))) bf16_t sV[AK * LDD];
+  __shared__ __attribute__((aligned(16))) bf16_t smem[4 * KV_ELEMS];  // [buf][K|V]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fg = lane >> 4;
   const int b = blockIdx.z, h = blockIdx.y;
@@ -277,22 +306,43 @@ __global__ __launch_bounds__(256) void k_attention(
   const bf16_t* vb = qb + (int64_t)2 * H * HD;
   constexpr float kLog2e = 1.4426950408889634f;
 
+  // DMA map (as the GEMM): wave instruction j (0..1) of wave w fills LDS rows
+  // (w*2 + j)*8 .. +8 of a tile; lane l lands in row r = base + l/8, physical
+  // chunk l%8, so it fetches logical chunk (l%8) ^ (r&7).  Keys beyond T are
+  // clamped to the last row (masked out of the softmax below).
+  int dr[2], dc[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    dr[j] = (wave * 2 + j) * 8 + (lane >> 3);
+    dc[j] = ((lane & 7) ^ (dr[j] & 7)) * 8;
+  }
+  auto dma = [&](int buf, int k0) {
+    bf16_t* dK = smem + buf * 2 * KV_ELEMS;
+    bf16_t* dV = dK + KV_ELEMS;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int key = k0 + dr[j] < T ? k0 + dr[j] : T - 1;
+      const int64_t off = (int64_t)key * tok_stride + dc[j];
+      const int slot = (wave * 2 + j) * 512;  // bf16 elements: 64 lanes x 8
+      __builtin_amdgcn_global_load_lds((gptr_t)(kb + off), (lptr_t)(dK + slot), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(vb + off), (lptr_t)(dV + slot), 16, 0, 0);
+    }
+  };
+  dma(0, 0);
+
   // Q fragments (B operand of S^T = K . Q^T): lane holds Q[q = fr][d = 8fg + j]
   bf16x8 qf[QT][2];
 #pragma unroll
   for (int i = 0; i < QT; ++i) {
     const int q = q0 + i * 16 + fr;
+    const int qc = q < T ? q : T - 1;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      if (q < T)
-        qf[i][ks] = *reinterpret_cast<const bf16x8*>(qb + (int64_t)q * tok_stride +
-                                                     ks * 32 + fg * 8);
-      else
-        qf[i][ks] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-    }
+    for (int ks = 0; ks < 2; ++ks)
+      qf[i][ks] = *reinterpret_cast<const bf16x8*>(qb + (int64_t)qc * tok_stride +
+                                                   ks * 32 + fg * 8);
   }
   f32x4 o[QT][4];  // [q tile][d tile]: O^T[d = 4fg + reg][q = fr]
-  float mrow[QT], lrow[QT];  // running max and sum per q = fr
+  float mrow[QT], lrow[QT];  // running max (log2 domain) and sum per q = fr
 #pragma unroll
   for (int i = 0; i < QT; ++i) {
     mrow[i] = -INFINITY;
@@ -300,102 +350,98 @@ __global__ __launch_bounds__(256) void k_attention(
 #pragma unroll
     for (int j = 0; j < 4; ++j) o[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  const float* brow = nullptr;
-  if (bias != nullptr) brow = bias + b * bias_sb + h * bias_sh;
-
-  // staging map: 64 rows x 64 d = 512 chunks of 8 bf16 per operand, 2 per thread
-  bf16x8 rk[2], rv[2];
-  auto load_tile = [&](int k0) {
+  const float* brow[QT];
+  if (HAS_BIAS) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int ch = tid + i * 256;
-      const int r = ch >> 3, dc = (ch & 7) * 8;
-      const int key = k0 + r;
-      if (key < T) {
-        rk[i] = *reinterpret_cast<const bf16x8*>(kb + (int64_t)key * tok_stride + dc);
-        rv[i] = *reinterpret_cast<const bf16x8*>(vb + (int64_t)key * tok_stride + dc);
-      } else {
-        rk[i] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-        rv[i] = rk[i];
-      }
+    for (int i = 0; i < QT; ++i) {
+      const int q = q0 + i * 16 + fr;
+      brow[i] = bias + b * bias_sb + h * bias_sh + (int64_t)(q < T ? q : T - 1) * T;
     }
-  };
-  load_tile(0);
-  // per-lane element offset of the transposing V read: lane 4q+p of a 16-lane
-  // group addresses row q, columns 4p..4p+3 of a 4 x 16 block (guide T10)
-  const int tr_off = (4 * fg + (fr >> 2)) * LDD + 4 * (fr & 3);
-
-  for (int k0 = 0; k0 < T; k0 += AK) {
-    __syncthreads();  // previous tile fully consumed
+  }
+  // fragment read offsets (bf16 elements) inside a tile
+  const int offK = fr * HD + ((fg ^ (fr & 7)) * 8);  // + kt*16*HD, ^32 for ks=1
+  int offV[4];  // transposing read: lane 4q+p of a 16-lane group addresses row
+                // q, columns 4p..4p+3 of a 4 x 16 block (guide T10)
+  {
+    const int row = 4 * fg + (fr >> 2);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int ch = tid + i * 256;
-      const int r = ch >> 3, dc = (ch & 7) * 8;
-      *reinterpret_cast<bf16x8*>(&sK[r * LDD + dc]) = rk[i];
-      *reinterpret_cast<bf16x8*>(&sV[r * LDD + dc]) = rv[i];
+    for (int j = 0; j < 4; ++j) {
+      const int chunk = 2 * j + ((fr & 3) >> 1);
+      offV[j] = row * HD + ((chunk ^ (row & 7)) * 8) + 4 * (fr & 1);
     }
-    __syncthreads();
-    if (k0 + AK < T) load_tile(k0 + AK);  // flies under the MFMAs below
+  }
 
+  const int nt = (T + AK - 1) / AK;
+  auto tile = [&](int t, auto tail_tag) {
+    constexpr bool TAIL = decltype(tail_tag)::value;
+    const int k0 = t * AK;
+    const bf16_t* sK = smem + (t & 1) * 2 * KV_ELEMS;
+    const bf16_t* sV = sK + KV_ELEMS;
     // S^T tiles: s[i][kt][reg] = S[q = i*16 + fr][key = kt*16 + 4fg + reg]
     f32x4 s[QT][4];
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
-      bf16x8 kf[2];
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-        kf[ks] = *reinterpret_cast<const bf16x8*>(
-            &sK[(kt * 16 + fr) * LDD + ks * 32 + fg * 8]);
+      const bf16x8 kf0 =
+          *reinterpret_cast<const bf16x8*>(sK + kt * 16 * HD + offK);
+      const bf16x8 kf1 =
+          *reinterpret_cast<const bf16x8*>(sK + kt * 16 * HD + (offK ^ 32));
 #pragma unroll
       for (int i = 0; i < QT; ++i) {
         f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
-        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[0], qf[i][0], a, 0, 0, 0);
-        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[1], qf[i][1], a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf0, qf[i][0], a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf1, qf[i][1], a, 0, 0, 0);
         s[i][kt] = a;
       }
     }
-    // bias, key mask, online softmax (statistics per q = fr,
-    // lane-local after a 4-group shuffle reduction)
-    const bool tail = k0 + AK > T;
 #pragma unroll
     for (int i = 0; i < QT; ++i) {
-      const int q = q0 + i * 16 + fr;
-      float mx = -INFINITY;
+      if (HAS_BIAS) {
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            int key = k0 + kt * 16 + fg * 4 + r;
+            if (TAIL) key = key < T ? key : T - 1;
+            s[i][kt][r] += brow[i][key];
+          }
+      }
+      if (TAIL) {
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (k0 + kt * 16 + fg * 4 + r >= T) s[i][kt][r] = -INFINITY;
+      }
+      float mx = s[i][0][0];
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int key = k0 + kt * 16 + fg * 4 + r;
-          float v = s[i][kt][r];
-          if (brow != nullptr && q < T && key < T) v += brow[(int64_t)q * T + key];
-          if (tail && key >= T) v = -INFINITY;
-          s[i][kt][r] = v;
-          mx = fmaxf(mx, v);
-        }
+        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[i][kt][r]);
       mx = fmaxf(mx, __shfl_xor(mx, 16));
       mx = fmaxf(mx, __shfl_xor(mx, 32));
-      const float mnew = fmaxf(mrow[i], mx);
+      // log2 domain: p = exp2(s*log2e - m), m = max(s)*log2e
+      const float mnew = fmaxf(mrow[i], mx * kLog2e);
       const float msafe = (mnew == -INFINITY) ? 0.f : mnew;
-      const float corr = __builtin_amdgcn_exp2f((mrow[i] - msafe) * kLog2e);
-      const float moff = -msafe * kLog2e;
+      const float corr = __builtin_amdgcn_exp2f(mrow[i] - msafe);
+      mrow[i] = mnew;
       float rs = 0.f;
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          // exp(s - m) = exp2(s*log2e - m*log2e): one FMA + one exp2
-          const float p = __builtin_amdgcn_exp2f(fmaf(s[i][kt][r], kLog2e, moff));
+          const float p = __builtin_amdgcn_exp2f(fmaf(s[i][kt][r], kLog2e, -msafe));
           s[i][kt][r] = p;
           rs += p;
         }
       rs += __shfl_xor(rs, 16);
       rs += __shfl_xor(rs, 32);
       lrow[i] = lrow[i] * corr + rs;
-      mrow[i] = mnew;
+      if (__any(corr != 1.f)) {  // wave-uniform: usually false after a few tiles
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        o[i][j][0] *= corr; o[i][j][1] *= corr;
-        o[i][j][2] *= corr; o[i][j][3] *= corr;
+        for (int j = 0; j < 4; ++j) {
+          o[i][j][0] *= corr; o[i][j][1] *= corr;
+          o[i][j][2] *= corr; o[i][j][3] *= corr;
+        }
       }
     }
     // O^T += V^T . P^T : MFMA k-slot (8fg + j) <-> key
@@ -406,20 +452,21 @@ __global__ __launch_bounds__(256) void k_attention(
       bf16x8 pf[QT];
 #pragma unroll
       for (int i = 0; i < QT; ++i) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          pf[i][r] = (short)f2bf(s[i][2 * kk][r]);
-          pf[i][4 + r] = (short)f2bf(s[i][2 * kk + 1][r]);
-        }
+        typedef unsigned __attribute__((ext_vector_type(4))) u32x4;
+        const u32x4 pk = {pack_bf16(s[i][2 * kk][0], s[i][2 * kk][1]),
+                          pack_bf16(s[i][2 * kk][2], s[i][2 * kk][3]),
+                          pack_bf16(s[i][2 * kk + 1][0], s[i][2 * kk + 1][1]),
+                          pack_bf16(s[i][2 * kk + 1][2], s[i][2 * kk + 1][3])};
+        pf[i] = __builtin_bit_cast(bf16x8, pk);
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         // V^T fragment of d tile j: column d = j*16 + fr of keys {4fg..4fg+3} of
         // key tiles 2kk and 2kk+1, delivered by the transposing read
         const bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-            (lds_bf16x4*)(&sV[(2 * kk) * 16 * LDD + j * 16 + tr_off]));
+            (lds_bf16x4*)(sV + (2 * kk) * 16 * HD + offV[j]));
         const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-            (lds_bf16x4*)(&sV[(2 * kk + 1) * 16 * LDD + j * 16 + tr_off]));
+            (lds_bf16x4*)(sV + (2 * kk + 1) * 16 * HD + offV[j]));
         bf16x8 vf;
         vf[0] = v0[0]; vf[1] = v0[1]; vf[2] = v0[2]; vf[3] = v0[3];
         vf[4] = v1[0]; vf[5] = v1[1]; vf[6] = v1[2]; vf[7] = v1[3];
@@ -428,6 +475,18 @@ __global__ __launch_bounds__(256) void k_attention(
           o[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[i], o[i][j], 0, 0, 0);
       }
     }
+  };
+
+  __syncthreads();  // tile 0 landed
+  for (int t = 0; t < nt; ++t) {
+    if (t + 1 < nt) dma((t + 1) & 1, (t + 1) * AK);  // flies under this tile
+    if (q0 < T) {  // waves past the last query only feed the DMA and barriers
+      if ((t + 1) * AK > T)
+        tile(t, std::true_type{});
+      else
+        tile(t, std::false_type{});
+    }
+    __syncthreads();  // next tile landed, this one fully consumed
   }
   // normalise and store: lane owns O[q = fr][d = j*16 + 4fg .. +3]
 #pragma unroll
@@ -438,12 +497,9 @@ __global__ __launch_bounds__(256) void k_attention(
     bf16_t* op = out + ((int64_t)b * T + q) * (int64_t)H * HD + (int64_t)h * HD;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      bf16x4 w4;
-      w4[0] = (short)f2bf(o[i][j][0] * inv);
-      w4[1] = (short)f2bf(o[i][j][1] * inv);
-      w4[2] = (short)f2bf(o[i][j][2] * inv);
-      w4[3] = (short)f2bf(o[i][j][3] * inv);
-      *reinterpret_cast<bf16x4*>(op + j * 16 + fg * 4) = w4;
+      const uint2 w2 = {pack_bf16(o[i][j][0] * inv, o[i][j][1] * inv),
+                        pack_bf16(o[i][j][2] * inv, o[i][j][3] * inv)};
+      *reinterpret_cast<uint2*>(op + j * 16 + fg * 4) = w2;
     }
   }
 }
@@ -492,31 +548,42 @@ int veon_vit_gemm(const void* a_bf16, const void* w_bf16, const float* bias,
   if (!al16(a_bf16) || !al16(w_bf16) || (bias && !al16(bias)) ||
       (gamma && !al16(gamma)) || (resid && !al16(resid)))
     return VEON_ERR_BAD_ARG;
-  const dim3 grid((unsigned)((N + BN - 1) / BN), (unsigned)((M + BM - 1) / BM));
   hipStream_t s = static_cast<hipStream_t>(stream);
   const bf16_t* A = static_cast<const bf16_t*>(a_bf16);
   const bf16_t* W = static_cast<const bf16_t*>(w_bf16);
   bf16_t* O = static_cast<bf16_t*>(out_bf16);
+  // tile height: 64 rows (3 workgroups per CU by LDS) unless that makes more
+  // than ~8 workgroups per CU, where the 128-row tile's halved weight traffic
+  // wins.  Measured at M = 5406 (profiles/r01_vit_bench.txt): these GEMMs are
+  // latency/occupancy-bound, not round-quantisation-bound -- 160/192-row tiles
+  // that bring N = 768 down to one round of workgroups were 20 % slower.
+  const int64_t ncol = (N + BN - 1) / BN;
+  const int mt = ((int64_t)((M + 63) / 64) * ncol > 8 * kNumCU) ? 4 : 2;
+  const dim3 grid((unsigned)ncol, (unsigned)((M + 32 * mt - 1) / (32 * mt)));
+#define VEON_LAUNCH_GEMM(EPI, MT)                                              \
+  do {                                                                         \
+    constexpr int lds = 2 * (32 * MT * BK + W_ELEMS) * (int)sizeof(bf16_t);    \
+    static const hipError_t attr = hipFuncSetAttribute(                        \
+        reinterpret_cast<const void*>(&k_gemm_bf16<EPI, MT>),                  \
+        hipFuncAttributeMaxDynamicSharedMemorySize, lds);                      \
+    if (attr != hipSuccess) return VEON_ERR_LAUNCH;                            \
+    hipLaunchKernelGGL((k_gemm_bf16<EPI, MT>), grid, dim3(256), lds, s, A, W,  \
+                       bias, gamma, resid, O, M, N, K);                        \
+  } while (0)
+#define VEON_LAUNCH_GEMM_MT(EPI)                                               \
+  do {                                                                         \
+    if (mt == 4) VEON_LAUNCH_GEMM(EPI, 4);                                     \
+    else VEON_LAUNCH_GEMM(EPI, 2);                                             \
+  } while (0)
   switch (epilogue) {
-    case EPI_BF16:
-      hipLaunchKernelGGL(k_gemm_bf16<EPI_BF16>, grid, dim3(256), 0, s, A, W, bias,
-                         gamma, resid, O, M, N, K);
-      break;
-    case EPI_GELU:
-      hipLaunchKernelGGL(k_gemm_bf16<EPI_GELU>, grid, dim3(256), 0, s, A, W, bias,
-                         gamma, resid, O, M, N, K);
-      break;
-    case EPI_QUICKGELU:
-      hipLaunchKernelGGL(k_gemm_bf16<EPI_QUICKGELU>, grid, dim3(256), 0, s, A, W,
-                         bias, gamma, resid, O, M, N, K);
-      break;
-    case EPI_RESID:
-      hipLaunchKernelGGL(k_gemm_bf16<EPI_RESID>, grid, dim3(256), 0, s, A, W, bias,
-                         gamma, resid, O, M, N, K);
-      break;
-    default:
-      return VEON_ERR_BAD_ARG;
+    case EPI_BF16: VEON_LAUNCH_GEMM_MT(EPI_BF16); break;
+    case EPI_GELU: VEON_LAUNCH_GEMM_MT(EPI_GELU); break;
+    case EPI_QUICKGELU: VEON_LAUNCH_GEMM_MT(EPI_QUICKGELU); break;
+    case EPI_RESID: VEON_LAUNCH_GEMM_MT(EPI_RESID); break;
+    default: return VEON_ERR_BAD_ARG;
   }
+#undef VEON_LAUNCH_GEMM_MT
+#undef VEON_LAUNCH_GEMM
   return launch_status();
 }
 
@@ -528,11 +595,14 @@ int veon_vit_attention(const void* qkv_bf16, const float* bias,
     return VEON_ERR_BAD_ARG;
   if (!al16(qkv_bf16) || !al16(out_bf16)) return VEON_ERR_BAD_ARG;
   const dim3 grid((unsigned)((T + 4 * AQ - 1) / (4 * AQ)), (unsigned)H, (unsigned)B);
-  hipLaunchKernelGGL(k_attention, grid, dim3(256), 0,
-                     static_cast<hipStream_t>(stream),
-                     static_cast<const bf16_t*>(qkv_bf16), bias,
-                     bias_batch_stride, bias_head_stride,
-                     static_cast<bf16_t*>(out_bf16), T, H);
+#define VEON_LAUNCH_ATT(BIAS)                                                  \
+  hipLaunchKernelGGL((k_attention<BIAS>), grid, dim3(256), 0,                  \
+                     static_cast<hipStream_t>(stream),                         \
+                     static_cast<const bf16_t*>(qkv_bf16), bias,               \
+                     bias_batch_stride, bias_head_stride,                      \
+                     static_cast<bf16_t*>(out_bf16), T, H)
+  if (bias != nullptr) VEON_LAUNCH_ATT(true); else VEON_LAUNCH_ATT(false);
+#undef VEON_LAUNCH_ATT
   return launch_status();
 }
 

@@ -52,13 +52,35 @@ def _can_fuse(ranks_bev, interval_starts, n_voxels):
     return ok and first >= 0 and last < n_voxels
 
 
+_HALF = (torch.float16, torch.bfloat16)
+
+
+def _feat_code(feat):
+    """``feat_dtype`` of the *_ex entry points (include/veon_hip.h)."""
+    if feat.dtype == torch.float16:
+        return _lib.FEAT_F16
+    if feat.dtype == torch.bfloat16:
+        return _lib.FEAT_BF16
+    return _lib.FEAT_F32
+
+
+def _inference_feat(feat, *others):
+    """The reference widens feat to fp32 before the kernel (bev_pool.py:21).
+    When nothing needs a gradient, fp16 / bf16 rows are instead widened inside
+    the kernel: same values, half the gather bytes, no fp32 copy."""
+    if feat.dtype in _HALF and not (torch.is_grad_enabled() and any(
+            t.requires_grad for t in (feat,) + others)):
+        return feat.contiguous()
+    return feat.contiguous().float()
+
+
 def _prep_inputs(depth, feat, ranks_depth, ranks_feat, ranks_bev,
                  interval_starts, interval_lengths):
     # casts of bev_pool.py:19-25 (no-ops for what the prepare produces)
     tag = getattr(interval_starts, '_veon_sorted', None)
     plan = getattr(interval_starts, '_veon_plan', None)
     depth = depth.contiguous().float()
-    feat = feat.contiguous().float()
+    feat = _inference_feat(feat, depth)
     ranks_bev = ranks_bev.contiguous().int()
     ranks_depth = ranks_depth.contiguous().int()
     ranks_feat = ranks_feat.contiguous().int()
@@ -109,13 +131,13 @@ def _fused_forward(depth, feat, ranks_depth, ranks_feat, ranks_bev,
         plan = build_plan(ranks_bev, interval_starts, B, Z * Y * X,
                           attach=False)
     with torch.cuda.device(dev):
-        st = _lib.lib().veon_bev_pool_v2_fwd_fused(
+        st = _lib.lib().veon_bev_pool_v2_fwd_fused_ex(
             C, interval_starts.numel(), B, Z * Y * X, _lib.ptr(depth),
-            _lib.ptr(feat), _lib.ptr(ranks_depth), _lib.ptr(ranks_feat),
-            _lib.ptr(ranks_bev), _lib.ptr(interval_starts),
-            _lib.ptr(interval_lengths), _lib.ptr(plan), _lib.ptr(out), layout,
-            _lib.stream_ptr(dev))
-    _lib.check(st, 'veon_bev_pool_v2_fwd_fused')
+            _lib.ptr(feat), _feat_code(feat), _lib.ptr(ranks_depth),
+            _lib.ptr(ranks_feat), _lib.ptr(ranks_bev),
+            _lib.ptr(interval_starts), _lib.ptr(interval_lengths),
+            _lib.ptr(plan), _lib.ptr(out), layout, _lib.stream_ptr(dev))
+    _lib.check(st, 'veon_bev_pool_v2_fwd_fused_ex')
     return out
 
 
@@ -154,6 +176,7 @@ class QuickCumsumCuda(torch.autograd.Function):
                                           ranks_bev, interval_starts,
                                           interval_lengths)
         B, Z, Y, X, C = [int(s) for s in bev_feat_shape]
+        feat = feat.float()
         if _can_fuse(ranks_bev, interval_starts, B * Z * Y * X):
             out = _fused_forward(depth, feat, ranks_depth, ranks_feat,
                                  ranks_bev, interval_starts, interval_lengths,
@@ -207,9 +230,14 @@ def bev_pool_v2(depth, feat, ranks_depth, ranks_feat, ranks_bev,
                                       interval_lengths)
     B, Z, Y, X, C = [int(s) for s in bev_feat_shape]
     if _can_fuse(ranks_bev, interval_starts, B * Z * Y * X):
+        if feat.dtype in _HALF:  # inference only, see _inference_feat
+            return _fused_forward(depth, feat, ranks_depth, ranks_feat,
+                                  ranks_bev, interval_starts, interval_lengths,
+                                  bev_feat_shape, _lib.LAYOUT_BCZYX)
         return _BevPoolV2Fused.apply(depth, feat, ranks_depth, ranks_feat,
                                      ranks_bev, bev_feat_shape,
                                      interval_starts, interval_lengths)
+    feat = feat.float()  # unsorted hand-made input: reference structure, fp32
     x = QuickCumsumCuda.apply(depth, feat, ranks_depth, ranks_feat, ranks_bev,
                               bev_feat_shape, interval_starts,
                               interval_lengths)
@@ -224,7 +252,7 @@ def bev_pool_v2_prepared(depth, feat, pre, bev_feat_shape):
     kernel, so the (unknown on the host) point / interval counts are not needed.
     An empty grid yields an all-zero (B,C,Z,Y,X) volume."""
     depth = depth.contiguous().float()
-    feat = feat.contiguous().float()
+    feat = _inference_feat(feat, depth)
     B, Z, Y, X, C = [int(s) for s in bev_feat_shape]
     if pre.batch != B or pre.vpb != Z * Y * X:
         raise _lib.VeonHipError('prepared ranks do not match bev_feat_shape')
@@ -234,13 +262,14 @@ def bev_pool_v2_prepared(depth, feat, pre, bev_feat_shape):
     dev = _lib.require_device(depth, feat, pre.ranks_bev)
     out = torch.empty((B, C, Z, Y, X), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
-        st = _lib.lib().veon_bev_pool_v2_fwd_fused(
+        st = _lib.lib().veon_bev_pool_v2_fwd_fused_ex(
             C, pre.interval_starts.numel(), B, Z * Y * X, _lib.ptr(depth),
-            _lib.ptr(feat), _lib.ptr(pre.ranks_depth), _lib.ptr(pre.ranks_feat),
-            _lib.ptr(pre.ranks_bev), _lib.ptr(pre.interval_starts),
-            _lib.ptr(pre.interval_lengths), _lib.ptr(pre.plan), _lib.ptr(out),
-            _lib.LAYOUT_BCZYX, _lib.stream_ptr(dev))
-    _lib.check(st, 'veon_bev_pool_v2_fwd_fused')
+            _lib.ptr(feat), _feat_code(feat), _lib.ptr(pre.ranks_depth),
+            _lib.ptr(pre.ranks_feat), _lib.ptr(pre.ranks_bev),
+            _lib.ptr(pre.interval_starts), _lib.ptr(pre.interval_lengths),
+            _lib.ptr(pre.plan), _lib.ptr(out), _lib.LAYOUT_BCZYX,
+            _lib.stream_ptr(dev))
+    _lib.check(st, 'veon_bev_pool_v2_fwd_fused_ex')
     return out
 
 
@@ -272,7 +301,7 @@ def bev_pool_v2_maxpool(depth, feat, ranks_depth, ranks_feat, ranks_bev,
     Bit-equal to max-pooling ``bev_pool_v2``'s output.  Intervals must be
     ascending in voxel rank (what the prepare produces)."""
     depth = depth.contiguous().float()
-    feat = feat.contiguous().float()
+    feat = _inference_feat(feat, depth)
     B, Z, Y, X, C = [int(s) for s in bev_feat_shape]
     dz, dy, dx = [int(v) for v in ds]
     dev = _lib.require_device(depth, feat, ranks_depth, ranks_feat, ranks_bev,
@@ -286,13 +315,13 @@ def bev_pool_v2_maxpool(depth, feat, ranks_depth, ranks_feat, ranks_bev,
     out = torch.empty((B, C, Z // dz, Y // dy, X // dx), dtype=torch.float32,
                       device=dev)
     with torch.cuda.device(dev):
-        st = _lib.lib().veon_bev_pool_v2_fwd_maxpool(
+        st = _lib.lib().veon_bev_pool_v2_fwd_maxpool_ex(
             C, interval_starts.numel(), B, Z, Y, X, dz, dy, dx, _lib.ptr(depth),
-            _lib.ptr(feat), _lib.ptr(ranks_depth), _lib.ptr(ranks_feat),
-            _lib.ptr(ranks_bev), _lib.ptr(interval_starts),
-            _lib.ptr(interval_lengths), _lib.ptr(table), _lib.ptr(out),
-            _lib.stream_ptr(dev))
-    _lib.check(st, 'veon_bev_pool_v2_fwd_maxpool')
+            _lib.ptr(feat), _feat_code(feat), _lib.ptr(ranks_depth),
+            _lib.ptr(ranks_feat), _lib.ptr(ranks_bev),
+            _lib.ptr(interval_starts), _lib.ptr(interval_lengths),
+            _lib.ptr(table), _lib.ptr(out), _lib.stream_ptr(dev))
+    _lib.check(st, 'veon_bev_pool_v2_fwd_maxpool_ex')
     return out
 
 
