@@ -272,6 +272,35 @@ int veon_vit_attention(const void *qkv_bf16, const float *bias,
                        void *out_bf16, int B, int T, int H, int head_dim,
                        void *stream);
 
+/*
+ * ---- 3x3x3 Conv3d body of the 3D alignment network ----
+ * Replaces the Conv3d + BN3d (+ReLU, + identity) of ResBlock3D
+ * (mmdet3d/models/semantic_net/side_adapter/align_net_occ3d.py:363-399), which
+ * the reference runs as mmcv ConvModules on cuDNN, by an implicit-GEMM MFMA
+ * kernel.  Volumes are channels-last bf16 in a zero-padded grid
+ * [B][Z+2][Y+2][X+2][C]; `*_padded` pointers address padded voxel (b=0,0,0,0)
+ * and the caller must keep veon_conv3d_guard_rows(Y, X) rows of C readable,
+ * finite bf16 values before that address and after the last padded row (the
+ * kernel reads them for halo outputs, which it then writes as zeros; it never
+ * writes guard rows).  w: [Cout][3][3][3][Cin] bf16 (torch's
+ * weight.permute(0,2,3,4,1)).  y = conv(in)*scale[n] + shift[n] (eval-mode
+ * BatchNorm folded by the caller; either may be NULL), + resid (optional,
+ * padded layout, Cout channels), ReLU if `relu`; halo rows of `out` are written
+ * as zeros so `out` is a valid padded input of the next conv.  Cin % 64 == 0,
+ * Cout % 8 == 0.  out must not alias in.
+ */
+int64_t veon_conv3d_guard_rows(int Y, int X);
+int veon_conv3d_k3_bf16(const void *in_padded, const void *w_bf16,
+                        const float *scale, const float *shift,
+                        const void *resid_padded, void *out_padded, int B, int Z,
+                        int Y, int X, int Cin, int Cout, int relu, void *stream);
+/* (B,C,Z,Y,X) fp32 <-> interior of the padded channels-last bf16 grid (the halo
+ * is not touched: allocate the grid zeroed once). */
+int veon_volume_pack_bf16(const float *ncdhw, void *padded, int B, int C, int Z,
+                          int Y, int X, void *stream);
+int veon_volume_unpack_f32(const void *padded, float *ncdhw, int B, int C, int Z,
+                           int Y, int X, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

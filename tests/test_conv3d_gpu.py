@@ -1,0 +1,123 @@
+"""GPU parity of the implicit-GEMM Conv3d body (csrc/conv3d.hip) against plain
+PyTorch fp32 ``conv3d`` / ``BatchNorm3d`` on the same bf16-rounded operands.
+
+Tolerance: operands are bf16 on both sides and accumulation is fp32, so the only
+differences are the fp32 summation order and the final bf16 rounding of the
+kernel's output: |got - want| <= 2^-7 * |want| + 2e-3 * rms(want) per element.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from veon_amd import _lib, conv3d_ops
+from veon_amd.models.semantic_net import AlignBody3D, ResBlock3D
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _bf(x):
+    return x.to(torch.bfloat16).float()
+
+
+def _close(got, want):
+    rms = want.pow(2).mean().sqrt().item() + 1e-12
+    err = (got - want).abs()
+    bound = want.abs() * 2.0 ** -7 + 2e-3 * rms
+    assert bool((err <= bound).all()), (err.max().item(), rms)
+
+
+def test_pack_unpack_round_trip_and_halo():
+    g = torch.Generator().manual_seed(0)
+    x = _bf(torch.randn(2, 72, 3, 5, 70, generator=g)).to(DEV)
+    vol = conv3d_ops.pack(x)
+    back = conv3d_ops.unpack(vol)
+    assert torch.equal(back, x)
+    grid = vol.rows.view(2, 5, 7, 72, 72).float()
+    assert torch.equal(grid[:, 1:-1, 1:-1, 1:-1].permute(0, 4, 1, 2, 3), x)
+    halo = grid.clone()
+    halo[:, 1:-1, 1:-1, 1:-1] = 0
+    assert float(halo.abs().sum()) == 0.0
+    assert float(vol.storage[:vol.guard].abs().sum()) == 0.0
+    assert float(vol.storage[vol.guard + vol.M:].abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize('B,Cin,Cout,Z,Y,X', [(1, 64, 64, 3, 5, 7), (2, 128, 72, 2, 9, 33),
+                                             (1, 64, 136, 1, 1, 1), (1, 192, 256, 4, 20, 21)])
+@pytest.mark.parametrize('mode', ['plain', 'bn_relu', 'bn_resid_relu'])
+def test_conv3d_matches_torch(B, Cin, Cout, Z, Y, X, mode):
+    g = torch.Generator().manual_seed(Cin + Cout + X)
+    x = _bf(torch.randn(B, Cin, Z, Y, X, generator=g)).to(DEV)
+    w = _bf(torch.randn(Cout, Cin, 3, 3, 3, generator=g) * (27 * Cin) ** -0.5).to(DEV)
+    scale = (torch.rand(Cout, generator=g) + 0.5).to(DEV)
+    shift = torch.randn(Cout, generator=g).to(DEV)
+    want = F.conv3d(x.double(), w.double(), padding=1).float()
+    vol = conv3d_ops.pack(x)
+    wp = conv3d_ops.pack_weight(w)
+    if mode == 'plain':
+        out = conv3d_ops.conv3d_k3(vol, wp)
+    elif mode == 'bn_relu':
+        want = F.relu(want * scale.view(1, -1, 1, 1, 1) + shift.view(1, -1, 1, 1, 1))
+        out = conv3d_ops.conv3d_k3(vol, wp, scale, shift, relu=True)
+    else:
+        if Cin != Cout:
+            pytest.skip('identity add needs Cin == Cout')
+        want = F.relu(want * scale.view(1, -1, 1, 1, 1) + shift.view(1, -1, 1, 1, 1) + x)
+        out = conv3d_ops.conv3d_k3(vol, wp, scale, shift, resid=vol, relu=True)
+    got = conv3d_ops.unpack(out)
+    _close(got, want)
+    # halo rows written as zeros, guard rows never written
+    grid = out.rows.view(B, Z + 2, Y + 2, X + 2, Cout).float().clone()
+    grid[:, 1:-1, 1:-1, 1:-1] = 0
+    assert float(grid.abs().sum()) == 0.0
+    assert float(out.storage[:out.guard].abs().sum()) == 0.0
+    assert float(out.storage[out.guard + out.M:].abs().sum()) == 0.0
+
+
+def test_veon_body_shape_against_torch_on_device():
+    """The actual VEON conv (256 -> 256 on 8 x 100 x 100, 283 GFLOP)."""
+    g = torch.Generator().manual_seed(1)
+    x = _bf(torch.randn(1, 256, 8, 100, 100, generator=g)).to(DEV)
+    w = _bf(torch.randn(256, 256, 3, 3, 3, generator=g) * (27 * 256) ** -0.5).to(DEV)
+    want = F.conv3d(x, w, padding=1)
+    got = conv3d_ops.unpack(conv3d_ops.conv3d_k3(conv3d_ops.pack(x),
+                                                 conv3d_ops.pack_weight(w)))
+    rel = ((got - want).norm() / want.norm()).item()
+    assert rel < 4e-3, rel  # bf16 output rounding (2^-9 rms) + MIOpen's own fp32 order
+
+
+def test_align_body_blocks_match_module_definition():
+    """Two ResBlock3D through the HIP stack vs the PyTorch definition with the
+    same (bf16-rounded) weights and non-trivial BN statistics."""
+    torch.manual_seed(3)
+    body = AlignBody3D(embed_dim=64, layer_depth=2)
+    for m in body.modules():
+        if isinstance(m, torch.nn.BatchNorm3d):
+            m.running_mean.normal_(0, 0.2)
+            m.running_var.uniform_(0.5, 1.5)
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.normal_(0, 0.2)
+        if isinstance(m, torch.nn.Conv3d):
+            m.weight.data = _bf(m.weight.data)
+    body = body.to(DEV).eval()
+    x = _bf(torch.randn(2, 64, 4, 10, 12)).to(DEV)
+    before = dict(_lib.CALLS)
+    with torch.no_grad():
+        got = body(x)
+        body.use_hip = False
+        want = body(x)
+    assert _lib.CALLS['veon_conv3d_k3_bf16'] - before.get('veon_conv3d_k3_bf16', 0) == 4
+    rel = ((got - want).norm() / want.norm()).item()
+    assert rel < 1.5e-2, rel  # three bf16 roundings of intermediate volumes
+    # partial ranges compose (the reference applies one block per fusion step)
+    body.use_hip = True
+    with torch.no_grad():
+        two = body(body(x, 0, 1), 1, 2)
+    assert ((two - got).norm() / got.norm()).item() < 1e-2
+
+
+def test_training_and_cpu_take_the_torch_definition():
+    blk = ResBlock3D(64, 64)
+    y = blk(torch.randn(1, 64, 2, 3, 3))
+    assert y.shape == (1, 64, 2, 3, 3) and y.requires_grad

@@ -172,3 +172,31 @@ def test_synthetic_rig_is_deterministic_and_sane():
     assert torch.allclose(r @ r.transpose(1, 2), eye, atol=1e-6)
     assert a['post_rots'][0, 0, 0, 0] == pytest.approx(0.44)
     assert a['post_trans'][0, 0].tolist() == [0.0, -140.0, 0.0]
+
+
+def test_align_body_state_dict_names_and_bn_fold():
+    """layers_3d_body.* keys follow mmcv's ConvModule layout so a VEON checkpoint
+    loads unchanged; the eval-mode BN fold equals BatchNorm3d."""
+    import torch
+    from veon_amd.models.semantic_net.align_net_body import AlignBody3D, ConvModule3d
+    body = AlignBody3D(embed_dim=64, layer_depth=2)
+    keys = set(body.state_dict())
+    for i in range(2):
+        for c in ('conv1', 'conv2'):
+            assert 'layers_3d_body.%d.%s.conv.weight' % (i, c) in keys
+            for n in ('weight', 'bias', 'running_mean', 'running_var'):
+                assert 'layers_3d_body.%d.%s.bn.%s' % (i, c, n) in keys
+    assert not any(k.endswith('conv.bias') for k in keys)
+    torch.manual_seed(0)
+    m = ConvModule3d(64, 64, act=False).eval()
+    m.bn.running_mean.normal_()
+    m.bn.running_var.uniform_(0.5, 2.0)
+    m.bn.weight.data.uniform_(0.5, 2.0)
+    m.bn.bias.data.normal_()
+    x = torch.randn(1, 64, 2, 4, 4)
+    scale = m.bn.weight / torch.sqrt(m.bn.running_var + m.bn.eps)
+    shift = m.bn.bias - m.bn.running_mean * scale
+    with torch.no_grad():
+        want = m(x)
+        got = m.conv(x) * scale.view(1, -1, 1, 1, 1) + shift.view(1, -1, 1, 1, 1)
+    assert torch.allclose(got, want, atol=1e-5)

@@ -1,0 +1,96 @@
+"""Torch-level wrappers of the Conv3d body kernels (csrc/conv3d.hip).
+
+``PaddedVolume`` owns the zero-padded channels-last bf16 grid
+[B][Z+2][Y+2][X+2][C] (plus the guard rows the kernel may read) that the
+implicit-GEMM conv consumes and produces.  Everything launches on the current
+stream; there is no CPU path.
+"""
+import torch
+
+from . import _lib
+
+
+class PaddedVolume:
+    """Channels-last bf16 volume with a zero halo.  ``rows`` is the
+    [M, C] view of the padded grid (M = B*(Z+2)*(Y+2)*(X+2)); the storage has
+    ``veon_conv3d_guard_rows`` zero rows before and after it."""
+
+    def __init__(self, B, C, Z, Y, X, device):
+        self.shape = (int(B), int(C), int(Z), int(Y), int(X))
+        B, C, Z, Y, X = self.shape
+        self.guard = int(_lib.lib().veon_conv3d_guard_rows(Y, X))
+        self.M = B * (Z + 2) * (Y + 2) * (X + 2)
+        self.storage = torch.zeros((self.M + 2 * self.guard, C),
+                                   dtype=torch.bfloat16, device=device)
+        self.rows = self.storage[self.guard:self.guard + self.M]
+
+    @property
+    def device(self):
+        return self.storage.device
+
+    def like(self, C=None):
+        B, C0, Z, Y, X = self.shape
+        return PaddedVolume(B, C0 if C is None else C, Z, Y, X, self.device)
+
+    def interior(self):
+        """(B,Z,Y,X,C) bf16 view of the un-padded voxels."""
+        B, C, Z, Y, X = self.shape
+        return self.rows.view(B, Z + 2, Y + 2, X + 2, C)[:, 1:-1, 1:-1, 1:-1]
+
+
+def pack(x, out=None):
+    """(B,C,Z,Y,X) fp32 -> PaddedVolume (bf16, round to nearest even)."""
+    dev = _lib.require_device(x)
+    x = x.contiguous().float()
+    B, C, Z, Y, X = x.shape
+    if out is None:
+        out = PaddedVolume(B, C, Z, Y, X, dev)
+    assert out.shape == tuple(x.shape)
+    with torch.cuda.device(dev):
+        st = _lib.lib().veon_volume_pack_bf16(_lib.ptr(x), _lib.ptr(out.rows), B, C,
+                                              Z, Y, X, _lib.stream_ptr(dev))
+    _lib.check(st, 'veon_volume_pack_bf16')
+    return out
+
+
+def unpack(vol, out=None):
+    """PaddedVolume -> (B,C,Z,Y,X) fp32."""
+    dev = _lib.require_device(vol.storage)
+    B, C, Z, Y, X = vol.shape
+    if out is None:
+        out = torch.empty(vol.shape, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        st = _lib.lib().veon_volume_unpack_f32(_lib.ptr(vol.rows), _lib.ptr(out), B,
+                                               C, Z, Y, X, _lib.stream_ptr(dev))
+    _lib.check(st, 'veon_volume_unpack_f32')
+    return out
+
+
+def pack_weight(w):
+    """nn.Conv3d weight (Cout,Cin,3,3,3) -> bf16 [Cout][3][3][3][Cin]."""
+    assert w.dim() == 5 and tuple(w.shape[2:]) == (3, 3, 3)
+    return w.detach().permute(0, 2, 3, 4, 1).contiguous().to(torch.bfloat16)
+
+
+def conv3d_k3(vol, w_packed, scale=None, shift=None, resid=None, relu=False,
+              out=None):
+    """3x3x3 stride-1 pad-1 convolution on a PaddedVolume with the fused
+    epilogue ``relu?(conv*scale + shift + resid?)`` -> PaddedVolume."""
+    dev = _lib.require_device(vol.storage, w_packed)
+    B, Cin, Z, Y, X = vol.shape
+    Cout = w_packed.shape[0]
+    assert w_packed.dtype == torch.bfloat16 and w_packed.is_contiguous()
+    assert w_packed.numel() == Cout * 27 * Cin
+    if out is None:
+        out = vol.like(Cout)
+    assert out.shape == (B, Cout, Z, Y, X) and out is not vol
+    if resid is not None:
+        assert resid.shape == out.shape
+    with torch.cuda.device(dev):
+        st = _lib.lib().veon_conv3d_k3_bf16(
+            _lib.ptr(vol.rows), _lib.ptr(w_packed), _lib.ptr(scale),
+            _lib.ptr(shift), _lib.ptr(None if resid is None else resid.rows),
+            _lib.ptr(out.rows), B, Z, Y, X, Cin, Cout, 1 if relu else 0,
+            _lib.stream_ptr(dev))
+    _lib.check(st, 'veon_conv3d_k3_bf16')
+    return out

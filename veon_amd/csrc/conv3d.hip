@@ -1,0 +1,332 @@
+// 3x3x3 Conv3d body of VEON's 3D alignment network on the MI355X matrix cores.
+//
+// The step right after the lift: AlignNetOcc3D runs
+// ResBlock3D x N on the max-pooled lift volume
+// (mmdet3d/models/semantic_net/side_adapter/align_net_occ3d.py:224-228, 363-399:
+// Conv3d 3x3x3 pad 1 no bias -> BN3d -> ReLU -> Conv3d -> BN3d, + identity,
+// ReLU; 256 -> 256 channels on 8 x 100 x 100 voxels, 283 GFLOP per conv).
+//
+// Implicit GEMM without an im2col and without boundary tests: the volume lives
+// channels-last in a ZERO-PADDED grid [B][Z+2][Y+2][X+2][C] (bf16).  In the
+// linear row index m of that grid every filter tap is a constant row offset
+//     off(dz,dy,dx) = ((dz-1)*(Y+2) + (dy-1))*(X+2) + (dx-1),
+// so   out[m][n] = sum_tap sum_c in[m + off(tap)][c] * w[n][tap][c]
+// is the dense GEMM of vit_block.hip whose activation slab simply starts at a
+// different row for every group of Cin/64 k-steps.  Outputs at halo rows are
+// written as zeros, so a conv's output buffer is directly the next conv's
+// padded input; tiles that lie entirely in a z-halo plane skip the contraction.
+// The cost is the halo's share of the rows that do run (4 % at 8x100x100).
+// Rows m + off can leave [0, M) for halo m only; the caller provides
+// veon_conv3d_guard_rows() readable rows before and after the grid instead of
+// per-lane clamps in the k-loop.
+//
+// Epilogue (fused, fp32): y = acc*scale[n] + shift[n] (BatchNorm3d in eval mode),
+// optional + residual (bf16, same padded layout), optional ReLU, -> bf16.
+#include "mfma_common.h"
+
+namespace {
+
+constexpr int CBN = 128, CBK = 64;
+constexpr int CW_ELEMS = CBN * CBK;
+
+template <int MT, bool RELU, bool RESID>
+__global__ __launch_bounds__(256) void k_conv3d_k3(
+    const bf16_t* __restrict__ in, const bf16_t* __restrict__ W,
+    const float* __restrict__ scale, const float* __restrict__ shift,
+    const bf16_t* __restrict__ resid, bf16_t* __restrict__ out, int planes,
+    int Zp, int Yp, int Xp, int Cin, int Cout) {
+  constexpr int BM = 32 * MT;
+  constexpr int A_ELEMS = BM * CBK;
+  constexpr int BUF_ELEMS = A_ELEMS + CW_ELEMS;
+  extern __shared__ __attribute__((aligned(16))) bf16_t smem[];  // [2][A|W]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int YX = Yp * Xp;
+  const int M = planes * YX;  // planes = B * Zp
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * CBN;
+  const int K = 27 * Cin;
+
+  // tile entirely inside z-halo planes: nothing to contract, store zeros
+  {
+    const int p0 = m0 / YX;
+    const int mlast = (m0 + BM - 1 < M ? m0 + BM - 1 : M - 1);
+    const int p1 = mlast / YX;
+    const int z0 = p0 % Zp, z1 = p1 % Zp;
+    const bool h0 = z0 == 0 || z0 == Zp - 1, h1 = z1 == 0 || z1 == Zp - 1;
+    if (h0 && h1 && p1 - p0 <= 1) {
+      // BM rows x 128 features of bf16 = BM*256 bytes, 16 bytes per lane-store
+      for (int i = tid; i < BM * 16; i += 256) {
+        const int r = i >> 4, c8 = (i & 15) * 8;
+        if (m0 + r < M && n0 + c8 < Cout)
+          *reinterpret_cast<uint4*>(out + (int64_t)(m0 + r) * Cout + n0 + c8) =
+              make_uint4(0u, 0u, 0u, 0u);
+      }
+      return;
+    }
+  }
+
+  // DMA map as k_gemm_bf16: a wave instruction fills 8 rows of a slab; lane l
+  // lands in row r = 8*piece + l/8, physical chunk l%8, and fetches logical
+  // chunk (l%8) ^ (r&7).  Activation rows are NOT clamped (guard rows).
+  const bf16_t* srcA[MT];
+  const bf16_t* srcW[4];
+#pragma unroll
+  for (int j = 0; j < MT; ++j) {
+    const int r = (wave * MT + j) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ (r & 7);
+    srcA[j] = in + (int64_t)(m0 + r) * Cin + c * 8;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int r = (wave * 4 + j) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ (r & 7);
+    const int gn = n0 + r < Cout ? n0 + r : Cout - 1;
+    srcW[j] = W + (int64_t)gn * K + c * 8;
+  }
+  const int cpk = Cin / CBK;  // k-steps per filter tap
+  auto a_off = [&](int kt) -> int64_t {
+    const int tap = kt / cpk;
+    const int cc = (kt - tap * cpk) * CBK;
+    const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
+    const int off = ((dz - 1) * Yp + (dy - 1)) * Xp + (dx - 1);
+    return (int64_t)off * Cin + cc;
+  };
+  auto dma = [&](int buf, int kt) {
+    bf16_t* dA = smem + buf * BUF_ELEMS;
+    bf16_t* dW = dA + A_ELEMS;
+    const int64_t ao = a_off(kt);
+#pragma unroll
+    for (int j = 0; j < MT; ++j)
+      __builtin_amdgcn_global_load_lds((gptr_t)(srcA[j] + ao),
+                                       (lptr_t)(dA + (wave * MT + j) * 512), 16, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      __builtin_amdgcn_global_load_lds((gptr_t)(srcW[j] + kt * CBK),
+                                       (lptr_t)(dW + (wave * 4 + j) * 512), 16, 0, 0);
+  };
+
+  f32x4 acc[MT][4];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  int offA[MT], offW[4];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int ra = wm * (16 * MT) + i * 16 + fr;
+    offA[i] = ra * CBK + ((fg ^ (ra & 7)) * 8);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int rw = wn * 64 + i * 16 + fr;
+    offW[i] = rw * CBK + ((fg ^ (rw & 7)) * 8);
+  }
+
+  const int nk = 27 * cpk;
+  dma(0, 0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) dma(buf ^ 1, kt + 1);
+    const bf16_t* tA = smem + buf * BUF_ELEMS;
+    const bf16_t* tW = tA + A_ELEMS;
+#pragma unroll
+    for (int ks = 0; ks < CBK / 32; ++ks) {
+      bf16x8 fa[MT], fw[4];
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+        fa[i] = *reinterpret_cast<const bf16x8*>(tA + (offA[i] ^ (ks * 32)));
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        fw[j] = *reinterpret_cast<const bf16x8*>(tW + (offW[j] ^ (ks * 32)));
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          // acc[i][j][reg] = C[voxel i*16 + fr][feature j*16 + 4*fg + reg]
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i],
+                                                               acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // epilogue: lane owns 4 consecutive features of one voxel per tile
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int m = m0 + wm * (16 * MT) + i * 16 + fr;
+    if (m >= M) continue;
+    const int p = m / YX, rem = m - p * YX;
+    const int y = rem / Xp, x = rem - y * Xp, z = p % Zp;
+    const bool interior = z >= 1 && z <= Zp - 2 && y >= 1 && y <= Yp - 2 &&
+                          x >= 1 && x <= Xp - 2;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wn * 64 + j * 16 + fg * 4;
+      if (n >= Cout) continue;
+      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      if (scale != nullptr) {
+        const float4 s4 = *reinterpret_cast<const float4*>(scale + n);
+        v[0] *= s4.x; v[1] *= s4.y; v[2] *= s4.z; v[3] *= s4.w;
+      }
+      if (shift != nullptr) {
+        const float4 b4 = *reinterpret_cast<const float4*>(shift + n);
+        v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+      }
+      if (RESID) {
+        const bf16x4 r4 =
+            *reinterpret_cast<const bf16x4*>(resid + (int64_t)m * Cout + n);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] += bf2f((bf16_t)r4[k]);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (RELU) v[k] = fmaxf(v[k], 0.f);
+        if (!interior) v[k] = 0.f;
+      }
+      const uint2 o = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
+      *reinterpret_cast<uint2*>(out + (int64_t)m * Cout + n) = o;
+    }
+  }
+}
+
+// (B,C,Z,Y,X) fp32 -> interior of the padded channels-last bf16 grid.  One
+// workgroup = one (b,z,y) row x 64 channels: reads are x-contiguous per channel,
+// writes are channel-contiguous per voxel, transposed through LDS.
+__global__ __launch_bounds__(256) void k_volume_pack(
+    const float* __restrict__ in, bf16_t* __restrict__ out, int C, int Z, int Y,
+    int X) {
+  __shared__ float t[64][65];
+  const int Yp = Y + 2, Xp = X + 2;
+  const int row = blockIdx.x;  // (b, z, y)
+  const int y = row % Y, z = (row / Y) % Z, b = row / (Y * Z);
+  const int c0 = blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int64_t cstride = (int64_t)Z * Y * X;
+  const float* ib = in + ((int64_t)b * C) * cstride + ((int64_t)z * Y + y) * X;
+  bf16_t* ob = out + ((((int64_t)b * (Z + 2) + z + 1) * Yp + y + 1) * Xp + 1) * C;
+  for (int x0 = 0; x0 < X; x0 += 64) {
+    for (int cc = ty; cc < 64; cc += 4)
+      t[cc][tx] = (x0 + tx < X && c0 + cc < C)
+                      ? ib[(int64_t)(c0 + cc) * cstride + x0 + tx]
+                      : 0.f;
+    __syncthreads();
+    for (int xx = ty; xx < 64; xx += 4)
+      if (x0 + xx < X && c0 + tx < C)
+        ob[(int64_t)(x0 + xx) * C + c0 + tx] = f2bf(t[tx][xx]);
+    __syncthreads();
+  }
+}
+
+// interior of the padded channels-last bf16 grid -> (B,C,Z,Y,X) fp32
+__global__ __launch_bounds__(256) void k_volume_unpack(
+    const bf16_t* __restrict__ in, float* __restrict__ out, int C, int Z, int Y,
+    int X) {
+  __shared__ float t[64][65];
+  const int Yp = Y + 2, Xp = X + 2;
+  const int row = blockIdx.x;
+  const int y = row % Y, z = (row / Y) % Z, b = row / (Y * Z);
+  const int c0 = blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int64_t cstride = (int64_t)Z * Y * X;
+  float* ob = out + ((int64_t)b * C) * cstride + ((int64_t)z * Y + y) * X;
+  const bf16_t* ib =
+      in + ((((int64_t)b * (Z + 2) + z + 1) * Yp + y + 1) * Xp + 1) * C;
+  for (int x0 = 0; x0 < X; x0 += 64) {
+    for (int xx = ty; xx < 64; xx += 4)
+      t[xx][tx] = (x0 + xx < X && c0 + tx < C)
+                      ? bf2f(ib[(int64_t)(x0 + xx) * C + c0 + tx])
+                      : 0.f;
+    __syncthreads();
+    for (int cc = ty; cc < 64; cc += 4)
+      if (x0 + tx < X && c0 + cc < C)
+        ob[(int64_t)(c0 + cc) * cstride + x0 + tx] = t[tx][cc];
+    __syncthreads();
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t veon_conv3d_guard_rows(int Y, int X) {
+  if (Y <= 0 || X <= 0) return 0;
+  // largest tap offset + the overhang of the last 128-row tile
+  return (int64_t)(Y + 2) * (X + 2) + (X + 2) + 1 + 128;
+}
+
+int veon_conv3d_k3_bf16(const void* in_padded, const void* w_bf16,
+                        const float* scale, const float* shift,
+                        const void* resid_padded, void* out_padded, int B, int Z,
+                        int Y, int X, int Cin, int Cout, int relu, void* stream) {
+  if (B <= 0 || Z <= 0 || Y <= 0 || X <= 0 || Cin <= 0 || Cout <= 0 ||
+      Cin % CBK != 0 || Cout % 8 != 0 || !in_padded || !w_bf16 || !out_padded)
+    return VEON_ERR_BAD_ARG;
+  if (!al16(in_padded) || !al16(w_bf16) || !al16(out_padded) ||
+      (scale && !al16(scale)) || (shift && !al16(shift)) ||
+      (resid_padded && !al16(resid_padded)))
+    return VEON_ERR_BAD_ARG;
+  const int64_t M = (int64_t)B * (Z + 2) * (Y + 2) * (X + 2);
+  if (M > 0x3fffffffLL) return VEON_ERR_BAD_ARG;
+  const int64_t ncol = (Cout + CBN - 1) / CBN;
+  const int mt = (((M + 63) / 64) * ncol > 8 * kNumCU) ? 4 : 2;
+  const dim3 grid((unsigned)ncol, (unsigned)((M + 32 * mt - 1) / (32 * mt)));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const bf16_t* I = static_cast<const bf16_t*>(in_padded);
+  const bf16_t* Wt = static_cast<const bf16_t*>(w_bf16);
+  const bf16_t* R = static_cast<const bf16_t*>(resid_padded);
+  bf16_t* O = static_cast<bf16_t*>(out_padded);
+  const int planes = B * (Z + 2);
+#define VEON_LAUNCH_CONV(MT, RELU, RESID)                                      \
+  do {                                                                         \
+    constexpr int lds = 2 * (32 * MT * CBK + CW_ELEMS) * (int)sizeof(bf16_t);  \
+    static const hipError_t attr = hipFuncSetAttribute(                        \
+        reinterpret_cast<const void*>(&k_conv3d_k3<MT, RELU, RESID>),          \
+        hipFuncAttributeMaxDynamicSharedMemorySize, lds);                      \
+    if (attr != hipSuccess) return VEON_ERR_LAUNCH;                            \
+    hipLaunchKernelGGL((k_conv3d_k3<MT, RELU, RESID>), grid, dim3(256), lds, s, \
+                       I, Wt, scale, shift, R, O, planes, Z + 2, Y + 2, X + 2, \
+                       Cin, Cout);                                             \
+  } while (0)
+#define VEON_LAUNCH_CONV_MT(RELU, RESID)                                       \
+  do {                                                                         \
+    if (mt == 4) VEON_LAUNCH_CONV(4, RELU, RESID);                             \
+    else VEON_LAUNCH_CONV(2, RELU, RESID);                                     \
+  } while (0)
+  if (relu) {
+    if (R) VEON_LAUNCH_CONV_MT(true, true); else VEON_LAUNCH_CONV_MT(true, false);
+  } else {
+    if (R) VEON_LAUNCH_CONV_MT(false, true); else VEON_LAUNCH_CONV_MT(false, false);
+  }
+#undef VEON_LAUNCH_CONV_MT
+#undef VEON_LAUNCH_CONV
+  return launch_status();
+}
+
+int veon_volume_pack_bf16(const float* ncdhw, void* padded, int B, int C, int Z,
+                          int Y, int X, void* stream) {
+  if (B <= 0 || C <= 0 || Z <= 0 || Y <= 0 || X <= 0 || !ncdhw || !padded)
+    return VEON_ERR_BAD_ARG;
+  const int64_t rows = (int64_t)B * Z * Y;
+  if (rows > 0x7fffffffLL) return VEON_ERR_BAD_ARG;
+  hipLaunchKernelGGL(k_volume_pack, dim3((unsigned)rows, (unsigned)((C + 63) / 64)),
+                     dim3(256), 0, static_cast<hipStream_t>(stream), ncdhw,
+                     static_cast<bf16_t*>(padded), C, Z, Y, X);
+  return launch_status();
+}
+
+int veon_volume_unpack_f32(const void* padded, float* ncdhw, int B, int C, int Z,
+                           int Y, int X, void* stream) {
+  if (B <= 0 || C <= 0 || Z <= 0 || Y <= 0 || X <= 0 || !ncdhw || !padded)
+    return VEON_ERR_BAD_ARG;
+  const int64_t rows = (int64_t)B * Z * Y;
+  if (rows > 0x7fffffffLL) return VEON_ERR_BAD_ARG;
+  hipLaunchKernelGGL(k_volume_unpack,
+                     dim3((unsigned)rows, (unsigned)((C + 63) / 64)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream),
+                     static_cast<const bf16_t*>(padded), ncdhw, C, Z, Y, X);
+  return launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,42 @@
+// Shared typedefs / helpers of the MFMA kernels (vit_block.hip, conv3d.hip).
+// Fragment convention for v_mfma_f32_16x16x32_bf16 (guide section 3): lane l
+// holds A[row l&15][k = 8(l>>4)+j] and B[k = 8(l>>4)+j][col l&15], j = 0..7;
+// D[row 4(l>>4)+reg][col l&15].
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/veon_hip.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(4))) short bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef unsigned short bf16_t;
+
+typedef const void __attribute__((address_space(1))) * gptr_t;
+typedef void __attribute__((address_space(3))) * lptr_t;
+
+typedef __bf16 __attribute__((ext_vector_type(2))) bf16pair;
+typedef float __attribute__((ext_vector_type(2))) f32x2;
+
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  // plain cast: hipcc emits v_cvt_pk_bf16_f32 (round to nearest even, NaN kept)
+  return __builtin_bit_cast(bf16_t, (__bf16)f);
+}
+__device__ __forceinline__ float bf2f(bf16_t h) {
+  return __uint_as_float(((unsigned)h) << 16);
+}
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, bf16pair));
+}
+
+inline int launch_status() {
+  return hipGetLastError() == hipSuccess ? VEON_OK : VEON_ERR_LAUNCH;
+}
+inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+constexpr int kNumCU = 256;  // MI355X
+
+}  // namespace

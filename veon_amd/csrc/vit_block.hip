@@ -18,31 +18,11 @@
 // V^T) as the MFMA "A" operand and the ACTIVATION (or Q, or P) as "B": the
 // accumulator then holds 4 consecutive output features of ONE token per lane
 // (16-byte epilogue accesses, per-token softmax statistics stay lane-local).
-#include <hip/hip_runtime.h>
-#include <stdint.h>
-
 #include <type_traits>
 
-#include "../../include/veon_hip.h"
+#include "mfma_common.h"
 
 namespace {
-
-typedef __attribute__((ext_vector_type(8))) short bf16x8;
-typedef __attribute__((ext_vector_type(4))) short bf16x4;
-typedef __attribute__((ext_vector_type(4))) float f32x4;
-typedef unsigned short bf16_t;
-
-__device__ __forceinline__ bf16_t f2bf(float f) {
-  // plain cast: hipcc emits v_cvt_pk_bf16_f32 (round to nearest even, NaN kept)
-  return __builtin_bit_cast(bf16_t, (__bf16)f);
-}
-__device__ __forceinline__ float bf2f(bf16_t h) {
-  return __uint_as_float(((unsigned)h) << 16);
-}
-
-inline int launch_status() {
-  return hipGetLastError() == hipSuccess ? VEON_OK : VEON_ERR_LAUNCH;
-}
 
 // ------------------------------------------------------------------ LayerNorm
 // one wave per token row; d <= 64 * kMaxPerLane
@@ -101,7 +81,6 @@ __global__ __launch_bounds__(256) void k_layernorm(
 // every ds_read_b128 of the 16x16x32 operand maps bank-conflict free.
 constexpr int BN = 128, BK = 64;
 constexpr int W_ELEMS = BN * BK;  // weight slab per buffer (16 KiB)
-constexpr int kNumCU = 256;       // MI355X
 
 enum { EPI_BF16 = 0, EPI_GELU = 1, EPI_QUICKGELU = 2, EPI_RESID = 3 };
 
@@ -124,8 +103,6 @@ __device__ __forceinline__ float quick_gelu(float x) {
   return x / (1.f + __expf(-1.702f * x));
 }
 
-typedef const void __attribute__((address_space(1))) * gptr_t;
-typedef void __attribute__((address_space(3))) * lptr_t;
 
 template <int EPI, int MT>
 __global__ __launch_bounds__(256) void k_gemm_bf16(
@@ -284,12 +261,6 @@ constexpr int AK = 64;        // keys per LDS tile
 constexpr int KV_ELEMS = AK * HD;  // one operand tile (8 KiB)
 
 typedef bf16x4 __attribute__((address_space(3))) lds_bf16x4;
-typedef __bf16 __attribute__((ext_vector_type(2))) bf16pair;
-typedef float __attribute__((ext_vector_type(2))) f32x2;
-
-__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
-  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, bf16pair));
-}
 
 template <bool HAS_BIAS>
 __global__ __launch_bounds__(256, 2) void k_attention(
@@ -512,7 +483,6 @@ __global__ __launch_bounds__(256) void k_cast_bf16(const float* __restrict__ in,
   if (i < n) out[i] = f2bf(in[i]);
 }
 
-inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 }  // namespace
 

@@ -1,3 +1,5 @@
+from .align_net_body import AlignBody3D, ConvModule3d, ResBlock3D
 from .clip_blocks import ClipVisualTrunk, ResidualAttentionBlock
 
-__all__ = ['ResidualAttentionBlock', 'ClipVisualTrunk']
+__all__ = ['ResidualAttentionBlock', 'ClipVisualTrunk', 'ResBlock3D',
+           'ConvModule3d', 'AlignBody3D']
