@@ -1,0 +1,46 @@
+#!/usr/bin/env python
+"""AlignNetOcc3D Conv3d body on the HIP implicit-GEMM kernel at the VEON shape
+(4 x ResBlock3D, 256 ch, 8x100x100): per-conv and whole-body time, TFLOP/s
+against the dense bf16 MFMA peak.  `--torch` adds the MIOpen baselines (slow)."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from veon_amd import conv3d_ops  # noqa: E402
+from veon_amd.models.semantic_net import AlignBody3D  # noqa: E402
+from tools.vit_bench import timeit, PEAK  # noqa: E402
+
+
+def main():
+    dev = 'cuda:0'
+    C, Z, Y, X = 256, 8, 100, 100
+    torch.manual_seed(0)
+    x = torch.randn(1, C, Z, Y, X, device=dev)
+    w = torch.randn(C, C, 3, 3, 3, device=dev) * (27 * C) ** -0.5
+    fl = 2.0 * Z * Y * X * C * C * 27
+    vol = conv3d_ops.pack(x)
+    wp = conv3d_ops.pack_weight(w)
+    out = vol.like()
+    sc = torch.ones(C, device=dev)
+    us = timeit(lambda: conv3d_ops.conv3d_k3(vol, wp, sc, sc, relu=True, out=out), iters=20)
+    print('conv3d_k3 BN+ReLU        %8.1f us  %6.1f TF/s (%4.1f%% of %.0f)' % (us, fl / us / 1e6, 100 * fl / us / 1e6 / PEAK, PEAK))
+    us = timeit(lambda: conv3d_ops.conv3d_k3(vol, wp, sc, sc, resid=vol, relu=True, out=out), iters=20)
+    print('conv3d_k3 BN+id+ReLU     %8.1f us  %6.1f TF/s (%4.1f%%)' % (us, fl / us / 1e6, 100 * fl / us / 1e6 / PEAK))
+    print('pack %.1f us  unpack %.1f us' % (timeit(lambda: conv3d_ops.pack(x, out=vol)),
+                                            timeit(lambda: conv3d_ops.unpack(vol))))
+    body = AlignBody3D(C, 4).to(dev).eval()
+    with torch.no_grad():
+        us = timeit(lambda: body(x), iters=10)
+        print('AlignBody3D 4 blocks     %8.1f us  %6.1f TF/s (%4.1f%%)  -> %.1f samples/s' % (
+            us, 8 * fl / us / 1e6, 100 * 8 * fl / us / 1e6 / PEAK, 1e6 / us))
+        if '--torch' in sys.argv:
+            body.use_hip = False
+            print('torch fp32 eager body    %8.1f us' % timeit(lambda: body(x), iters=3))
+            b16, xb = body.bfloat16(), x.bfloat16()
+            print('torch bf16 eager body    %8.1f us' % timeit(lambda: b16(xb), iters=3))
+
+
+if __name__ == '__main__':
+    main()
