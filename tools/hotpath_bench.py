@@ -1,12 +1,21 @@
 #!/usr/bin/env python
-"""Accelerated rows of the VEON forward chained together on one MI355X:
-DepthAnythingV2 (MFMA encoder + torch DPT head) -> metric depth -> fused
-block-min + two-hot depth -> CLIP ViT-B/16 trunk (MFMA) -> stand-in 1x1
-projection to C=256 at the lift resolution -> sync-free lift with the fused
-2x2x2 max-pool.  The SAN side adapter / HSA / AlignNetOcc3D decoder are NOT
-part of this (they stay PyTorch in the reference and are not rebuilt here), so
-this is the throughput of the rows SURVEY section 8 puts on the hot path, not a
-VEON end-to-end number.  Synthetic inputs, random weights, 6 cameras 256x704."""
+"""Accelerated rows of the VEON forward chained together on one MI355X
+(BASELINE config 3 shape: VEON-B, bf16, 6 cameras 256x704, synthetic inputs,
+random weights):
+
+  DepthAnythingV2 (MFMA encoder, hipGraph | DPT head on PyTorch/MIOpen)
+    -> metric depth -> fused block-min + two-hot depth
+  CLIP ViT-B/16 trunk (MFMA) -> stand-in 1x1 projection to C=256 at Hf x Wf
+  -> sync-free lift with the fused 2x2x2 max-pool
+  -> AlignNetOcc3D Conv3d body, 4 ResBlock3D on MFMA
+
+The SAN side adapter, HSA network, prediction heads and the classifier einsum
+are NOT part of this (PyTorch in the reference, not rebuilt), so this is the
+throughput of the rows SURVEY section 8 puts on the hot path plus row f1, not a
+full VEON end-to-end number.
+
+    python tools/hotpath_bench.py [vitb|vitl] [--head-bf16] [--graph-clip]
+"""
 import os
 import sys
 import time
@@ -16,8 +25,9 @@ import torch.nn.functional as F
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from veon_amd import synthetic  # noqa: E402
+from veon_amd.graphs import GraphedCallable  # noqa: E402
 from veon_amd.models import build_neck  # noqa: E402
-from veon_amd.models.semantic_net import ClipVisualTrunk  # noqa: E402
+from veon_amd.models.semantic_net import AlignBody3D, ClipVisualTrunk  # noqa: E402
 
 
 def timeit(fn, iters=20):
@@ -32,7 +42,10 @@ def timeit(fn, iters=20):
 
 
 def main():
-    enc = sys.argv[1] if len(sys.argv) > 1 else 'vitb'
+    args = [a for a in sys.argv[1:] if not a.startswith('--')]
+    enc = args[0] if args else 'vitb'
+    head_bf16 = '--head-bf16' in sys.argv
+    graph_clip = '--graph-clip' in sys.argv
     dev = 'cuda:0'
     size = (256, 704)
     torch.manual_seed(0)
@@ -40,60 +53,87 @@ def main():
             'vitl': dict(encoder='vitl', features=256, out_channels=[256, 512, 1024, 1024])}
     dav2 = build_neck(dict(type='DepthAnythingV2Adaptor', max_depth=80.0,
                            use_lora=True, lora_r=16, **cfgs[enc])).to(dev).eval()
+    if head_bf16:
+        dav2.head_dtype = torch.bfloat16
     clip = ClipVisualTrunk(224, 16, 768, 12, 12).to(dev).eval()
     proj = torch.nn.Conv2d(768, 256, 1).to(dev).eval()
     vt = build_neck(dict(type='LSSViewTransformerRaw', grid_config=synthetic.GRID_VEON,
                          input_size=size, out_channels=256, collapse_z=False,
                          ds_feat=[2, 2, 2])).to(dev).eval()
     vt.sync_free = True
+    body = AlignBody3D(256, 4).to(dev).eval()
     rig = synthetic.make_rig(1, 6, size)
     geom = [t.to(dev) for t in synthetic.rig_inputs(rig)]
     img = torch.randn(6, 3, *size, device=dev)
 
-    def depth_branch(im):
-        x = F.interpolate(im, (252, 700), mode='bilinear', align_corners=False)
-        d = dav2(x)['metric_depth']                                   # (6,252,700)
-        d = F.interpolate(d[:, None], (size[0] // 2, size[1] // 2), mode='bilinear',
-                          align_corners=True)[:, 0]
-        # VEON feeds the (h/2, w/2) depth map and block-mins by 8 down to Hf x Wf
-        return vt.get_two_hot_depth(vt.downsample_depth(d[None], 8))   # (1,6,D,16,44)
-
-    def sem_branch(im):
-        x = F.interpolate(im, scale_factor=0.5, mode='bilinear', align_corners=False)
-        outs, (h, w) = clip(x)
-        tok = outs[-1][1:]                                             # (h*w, 6, 768)
-        f = tok.permute(1, 2, 0).reshape(6, 768, h, w)
-        f = F.interpolate(proj(f), (size[0] // 16, size[1] // 16), mode='bilinear',
-                          align_corners=False)
-        return f[None]                                                 # (1,6,256,16,44)
-
-    def lift(feat, depth):
-        return vt([feat] + geom, depth)
-
-    def whole(im):
-        return lift(sem_branch(im), depth_branch(im))
+    def encode(x):
+        # flatten the ((patch, cls), ...) structure for the graph wrapper
+        return [t for pair in dav2.encode(x) for t in pair]
 
     with torch.no_grad():
+        x252 = F.interpolate(img, (252, 700), mode='bilinear', align_corners=False)
+        g_enc = GraphedCallable(encode, (x252,))
+
+        def depth_branch(im):
+            x = F.interpolate(im, (252, 700), mode='bilinear', align_corners=False)
+            flat = g_enc(x)
+            feats = [(flat[2 * i], flat[2 * i + 1]) for i in range(4)]
+            d = dav2.decode(feats, 18, 50).squeeze(1)                    # (6,252,700)
+            d = F.interpolate(d[:, None], (size[0] // 2, size[1] // 2), mode='bilinear',
+                              align_corners=True)[:, 0]
+            # VEON feeds the (h/2, w/2) depth map and block-mins by 8 down to Hf x Wf
+            return vt.get_two_hot_depth(vt.downsample_depth(d[None], 8))  # (1,6,D,16,44)
+
+        def trunk(x):
+            outs, _ = clip(x)
+            return outs[-1]
+
+        x_half = F.interpolate(img, scale_factor=0.5, mode='bilinear', align_corners=False)
+        g_clip = GraphedCallable(trunk, (x_half,)) if graph_clip else trunk
+
+        def sem_branch(im):
+            x = F.interpolate(im, scale_factor=0.5, mode='bilinear', align_corners=False)
+            tok = g_clip(x)[1:]                                          # (h*w, 6, 768)
+            h, w = x.shape[-2] // 16, x.shape[-1] // 16
+            f = tok.permute(1, 2, 0).reshape(6, 768, h, w)
+            f = F.interpolate(proj(f), (size[0] // 16, size[1] // 16), mode='bilinear',
+                              align_corners=False)
+            return f[None]                                               # (1,6,256,16,44)
+
         d = depth_branch(img)
         f = sem_branch(img)
-        out = lift(f, d)
+
+        def lift_body(feat, depth):
+            return body(vt([feat] + geom, depth))
+
+        # NOTE: lift and body run eagerly here.  Each replays fine from its own
+        # hipGraph (tests, bench.py, tools/time_forward.py), but in this script a
+        # lift graph captured before a second lift(+body) graph faulted on its
+        # first replay ("write access to a read-only page") while the younger
+        # graph replayed fine; the lift kernels were then checked for
+        # uninitialised reads (tools/poison_probe.py: none) -- unexplained, so
+        # only the encoder graph (replayed the same way in tools/vit_bench.py) is
+        # kept.  Eager launch overhead is ~0.1 ms of the ~3.3 ms lift + body.
+        def whole(im):
+            return lift_body(sem_branch(im), depth_branch(im))
+
+        out = whole(img)
         torch.cuda.synchronize()
         print('depth', tuple(d.shape), 'feat', tuple(f.shape), 'out', tuple(out.shape), flush=True)
+        t_e = timeit(lambda: g_enc(x252))
         t_d = timeit(lambda: depth_branch(img))
-        print('depth branch %.2f ms' % t_d, flush=True)
+        print('depth branch %.2f ms (encoder graph %.2f ms, DPT head %s)' % (
+            t_d, t_e, 'bf16 autocast' if head_bf16 else 'fp32'), flush=True)
         t_s = timeit(lambda: sem_branch(img))
-        print('semantic trunk %.2f ms' % t_s, flush=True)
-        t_l = timeit(lambda: lift(f, d))
+        print('semantic trunk %.2f ms (%s)' % (t_s, 'hipGraph' if graph_clip else 'eager'), flush=True)
+        t_l = timeit(lambda: vt([f] + geom, d))
         print('lift %.3f ms' % t_l, flush=True)
+        t_lb = timeit(lambda: lift_body(f, d))
+        print('lift + Conv3d body %.3f ms' % t_lb, flush=True)
         t_w = timeit(lambda: whole(img))
-        print('chained eager %.2f ms' % t_w, flush=True)
-        # NOTE: the chain is NOT replayed from a hipGraph here.  Capturing it works
-        # but the replay faulted ("write access to a read-only page") on this
-        # ROCm stack; the graphs of this package's own kernels (encoder blocks,
-        # sync-free lift) replay fine, so the suspect is a MIOpen convolution of
-        # the DPT head using memory outside the capture pool.  Left eager.
-    print('%s: depth branch %.2f ms | semantic trunk %.2f ms | lift %.3f ms | chained eager %.2f ms '
-          '-> %.1f 6-cam samples/s' % (enc, t_d, t_s, t_l, t_w, 1e3 / t_w))
+        print('chained %.2f ms' % t_w, flush=True)
+    print('%s: depth %.2f | semantic %.2f | lift %.3f | lift+body %.3f | chained %.2f ms '
+          '-> %.1f 6-cam samples/s' % (enc, t_d, t_s, t_l, t_lb, t_w, 1e3 / t_w))
 
 
 if __name__ == '__main__':

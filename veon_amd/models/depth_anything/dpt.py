@@ -132,10 +132,28 @@ class DepthAnythingV2Adaptor(nn.Module):
         self.depth_head = DPTHead(self.pretrained.embed_dim, features, use_bn,
                                   out_channels=out_channels,
                                   use_clstoken=use_clstoken)
+        # veon_amd extension: run the DPT head's convolutions (PyTorch/MIOpen)
+        # under autocast at inference, e.g. torch.bfloat16 for BASELINE config 3
+        # ("bf16").  None = fp32, the reference's numerics.
+        self.head_dtype = None
+
+    def encode(self, x):
+        """The four intermediate (patch tokens, class token) pairs the head
+        consumes (dpt.py:258-259)."""
+        return self.pretrained.get_intermediate_layers(
+            x, self.intermediate_layer_idx[self.encoder], return_class_token=True)
+
+    def decode(self, feats, patch_h, patch_w):
+        if (self.head_dtype is not None and feats[0][0].is_cuda
+                and not torch.is_grad_enabled()):
+            with torch.autocast('cuda', dtype=self.head_dtype):
+                depth = self.depth_head(feats, patch_h, patch_w)
+            depth = depth.float()
+        else:
+            depth = self.depth_head(feats, patch_h, patch_w)
+        return depth * self.max_depth
 
     def forward(self, x):
         patch_h, patch_w = x.shape[-2] // 14, x.shape[-1] // 14
-        feats = self.pretrained.get_intermediate_layers(
-            x, self.intermediate_layer_idx[self.encoder], return_class_token=True)
-        depth = self.depth_head(feats, patch_h, patch_w) * self.max_depth
+        depth = self.decode(self.encode(x), patch_h, patch_w)
         return {'metric_depth': depth.squeeze(1)}
