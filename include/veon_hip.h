@@ -273,6 +273,37 @@ int veon_vit_attention(const void *qkv_bf16, const float *bias,
                        void *stream);
 
 /*
+ * One whole pre-norm transformer block on the fp32 residual stream x [B*T, d]
+ * (in place): x += g1*(proj(attn(LN1(x)))), x += g2*(fc2(act(fc1(LN2(x))))) --
+ * the DINOv2 block (dinov2_layers/block.py:85-110; g = LayerScale) and the CLIP
+ * ResidualAttentionBlock (g = NULL, act = QuickGELU).  Seven launches behind
+ * one call, so an eager host pays one call per block instead of seven.
+ * Weights: bf16 [out,in] row-major with q pre-scaled, fp32 vectors; gamma1/2
+ * may be NULL.  act = 1 (GELU erf) or 2 (QuickGELU) -- the veon_vit_gemm
+ * epilogue codes.  workspace: veon_vit_block_workspace_bytes(), 256-B aligned.
+ */
+typedef struct veon_vit_block_weights {
+  const float *ln1_w, *ln1_b;
+  const void *w_qkv;
+  const float *b_qkv;
+  const void *w_proj;
+  const float *b_proj, *gamma1;
+  const float *ln2_w, *ln2_b;
+  const void *w_fc1;
+  const float *b_fc1;
+  const void *w_fc2;
+  const float *b_fc2, *gamma2;
+  float ln1_eps, ln2_eps;
+  int mlp_dim, act;
+} veon_vit_block_weights;
+int64_t veon_vit_block_workspace_bytes(int B, int T, int d, int mlp_dim);
+int veon_vit_block(float *x, const veon_vit_block_weights *w,
+                   const float *attn_bias, int64_t bias_batch_stride,
+                   int64_t bias_head_stride, void *workspace,
+                   int64_t workspace_bytes, int B, int T, int d, int H,
+                   void *stream);
+
+/*
  * ---- 3x3x3 Conv3d body of the 3D alignment network ----
  * Replaces the Conv3d + BN3d (+ReLU, + identity) of ResBlock3D
  * (mmdet3d/models/semantic_net/side_adapter/align_net_occ3d.py:363-399), which

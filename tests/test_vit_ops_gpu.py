@@ -111,3 +111,46 @@ def test_attention_with_bias_and_masking():
     got = vit_ops.attention(qkv, H, b1).float()
     torch.testing.assert_close(got, _ref_attention(qkv, H, b1), rtol=2 ** -7,
                                atol=4e-3)
+
+
+@pytest.mark.parametrize('act,with_gamma,with_bias', [(vit_ops.EPI_GELU, True, False),
+                                                      (vit_ops.EPI_QUICKGELU, False, True)])
+def test_whole_block_call_equals_the_seven_ops(act, with_gamma, with_bias):
+    """veon_vit_block (one native call per block) is exactly the sequence
+    LN -> qkv -> attention -> proj(+res) -> LN -> fc1(act) -> fc2(+res)."""
+    torch.manual_seed(5)
+    B, T, H = 2, 77, 2
+    d, mlp = H * 64, 4 * H * 64
+    dev = DEV
+
+    def vec(n, s=1.0):
+        return (torch.randn(n, device=dev) * s).contiguous()
+
+    def mat(n, k):
+        return vit_ops.to_bf16(torch.randn(n, k, device=dev) * k ** -0.5)
+    n1 = (vec(d, 0.1) + 1, vec(d, 0.1), 1e-6)
+    n2 = (vec(d, 0.1) + 1, vec(d, 0.1), 1e-5)
+    w_qkv, b_qkv, w_proj, b_proj = mat(3 * d, d), vec(3 * d, 0.1), mat(d, d), vec(d, 0.1)
+    w_fc1, b_fc1, w_fc2, b_fc2 = mat(mlp, d), vec(mlp, 0.1), mat(d, mlp), vec(d, 0.1)
+    g1 = vec(d, 0.5) if with_gamma else None
+    g2 = vec(d, 0.5) if with_gamma else None
+    bias = torch.randn(B, H, T, T, device=dev) if with_bias else None
+    x0 = torch.randn(B * T, d, device=dev)
+    # reference: the individual ops
+    x = x0.clone()
+    h = vit_ops.layernorm(x, *n1)
+    qkv = vit_ops.linear(h, w_qkv, b_qkv)
+    o = vit_ops.attention(qkv.view(B, T, -1), H, bias)
+    vit_ops.linear_residual_(x, o.view(B * T, -1), w_proj, b_proj, g1)
+    h = vit_ops.layernorm(x, *n2)
+    u = vit_ops.linear(h, w_fc1, b_fc1, act)
+    vit_ops.linear_residual_(x, u, w_fc2, b_fc2, g2)
+    # one call
+    w = vit_ops.BlockWeights(H, n1, w_qkv, b_qkv, w_proj, b_proj, g1, n2, w_fc1,
+                             b_fc1, w_fc2, b_fc2, g2, act)
+    ws = vit_ops.block_workspace(B, T, d, mlp, dev)
+    y = vit_ops.block_forward_(x0.clone(), w, B, T, ws, bias)
+    assert torch.equal(x, y)
+    # too-small workspace is refused, not overrun
+    with pytest.raises(Exception):
+        vit_ops.block_forward_(x0.clone(), w, B, T, ws[:ws.numel() // 2], bias)

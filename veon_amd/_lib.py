@@ -20,6 +20,22 @@ _ci = ctypes.c_int
 _i64 = ctypes.c_int64
 _cf = ctypes.c_float
 
+
+
+class VitBlockWeights(ctypes.Structure):
+    """``veon_vit_block_weights`` of include/veon_hip.h."""
+    _fields_ = [('ln1_w', ctypes.c_void_p), ('ln1_b', ctypes.c_void_p),
+                ('w_qkv', ctypes.c_void_p), ('b_qkv', ctypes.c_void_p),
+                ('w_proj', ctypes.c_void_p), ('b_proj', ctypes.c_void_p),
+                ('gamma1', ctypes.c_void_p),
+                ('ln2_w', ctypes.c_void_p), ('ln2_b', ctypes.c_void_p),
+                ('w_fc1', ctypes.c_void_p), ('b_fc1', ctypes.c_void_p),
+                ('w_fc2', ctypes.c_void_p), ('b_fc2', ctypes.c_void_p),
+                ('gamma2', ctypes.c_void_p),
+                ('ln1_eps', ctypes.c_float), ('ln2_eps', ctypes.c_float),
+                ('mlp_dim', ctypes.c_int), ('act', ctypes.c_int)]
+
+
 _SIGNATURES = {
     'veon_abi_version': (_ci, []),
     'veon_status_string': (ctypes.c_char_p, [_ci]),
@@ -39,6 +55,8 @@ _SIGNATURES = {
     'veon_vit_layernorm': (_ci, [_vp, _vp, _vp, _vp, _ci, _ci, _cf, _vp]),
     'veon_vit_gemm': (_ci, [_vp] * 6 + [_ci] * 4 + [_vp]),
     'veon_vit_attention': (_ci, [_vp, _vp, _i64, _i64, _vp, _ci, _ci, _ci, _ci, _vp]),
+    'veon_vit_block_workspace_bytes': (_i64, [_ci] * 4),
+    'veon_vit_block': (_ci, [_vp, _vp, _vp, _i64, _i64, _vp, _i64] + [_ci] * 4 + [_vp]),
     'veon_conv3d_guard_rows': (_i64, [_ci, _ci]),
     'veon_conv3d_k3_bf16': (_ci, [_vp] * 6 + [_ci] * 7 + [_vp]),
     'veon_volume_pack_bf16': (_ci, [_vp, _vp] + [_ci] * 5 + [_vp]),

@@ -576,4 +576,58 @@ int veon_vit_attention(const void* qkv_bf16, const float* bias,
   return launch_status();
 }
 
+
+int64_t veon_vit_block_workspace_bytes(int B, int T, int d, int mlp_dim) {
+  if (B <= 0 || T <= 0 || d <= 0 || mlp_dim <= 0) return 0;
+  // h [M,d] + qkv [M,3d] + o [M,d] + u [M,mlp], bf16, each 256-B aligned
+  const int64_t M = (int64_t)B * T;
+  auto al = [](int64_t v) { return (v + 255) / 256 * 256; };
+  return al(M * d * 2) + al(M * 3 * d * 2) + al(M * d * 2) + al(M * mlp_dim * 2);
+}
+
+int veon_vit_block(float* x, const veon_vit_block_weights* w,
+                   const float* attn_bias, int64_t bias_batch_stride,
+                   int64_t bias_head_stride, void* workspace,
+                   int64_t workspace_bytes, int B, int T, int d, int H,
+                   void* stream) {
+  if (!x || !w || !workspace || B <= 0 || T <= 0 || d <= 0 || H <= 0 ||
+      d != H * HD || w->mlp_dim <= 0)
+    return VEON_ERR_BAD_ARG;
+  if (w->act != EPI_GELU && w->act != EPI_QUICKGELU) return VEON_ERR_BAD_ARG;
+  if (workspace_bytes < veon_vit_block_workspace_bytes(B, T, d, w->mlp_dim))
+    return VEON_ERR_WORKSPACE;
+  if ((reinterpret_cast<uintptr_t>(workspace) & 255u) != 0) return VEON_ERR_BAD_ARG;
+  const int64_t M64 = (int64_t)B * T;
+  if (M64 > 0x7fffffffLL) return VEON_ERR_BAD_ARG;
+  const int M = (int)M64;
+  auto al = [](int64_t v) { return (v + 255) / 256 * 256; };
+  char* p = static_cast<char*>(workspace);
+  void* h = p;
+  p += al(M64 * d * 2);
+  void* qkv = p;
+  p += al(M64 * 3 * d * 2);
+  void* o = p;
+  p += al(M64 * d * 2);
+  void* u = p;
+  int st;
+  if ((st = veon_vit_layernorm(x, w->ln1_w, w->ln1_b, h, M, d, w->ln1_eps, stream)))
+    return st;
+  if ((st = veon_vit_gemm(h, w->w_qkv, w->b_qkv, nullptr, nullptr, qkv, M, 3 * d, d,
+                          EPI_BF16, stream)))
+    return st;
+  if ((st = veon_vit_attention(qkv, attn_bias, bias_batch_stride, bias_head_stride,
+                               o, B, T, H, HD, stream)))
+    return st;
+  if ((st = veon_vit_gemm(o, w->w_proj, w->b_proj, w->gamma1, x, nullptr, M, d, d,
+                          EPI_RESID, stream)))
+    return st;
+  if ((st = veon_vit_layernorm(x, w->ln2_w, w->ln2_b, h, M, d, w->ln2_eps, stream)))
+    return st;
+  if ((st = veon_vit_gemm(h, w->w_fc1, w->b_fc1, nullptr, nullptr, u, M, w->mlp_dim,
+                          d, w->act, stream)))
+    return st;
+  return veon_vit_gemm(u, w->w_fc2, w->b_fc2, w->gamma2, x, nullptr, M, d,
+                       w->mlp_dim, EPI_RESID, stream);
+}
+
 }  // extern "C"

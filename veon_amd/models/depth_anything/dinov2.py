@@ -178,18 +178,11 @@ class _HipBlockWeights:
                    if isinstance(blk.ls1, LayerScale) else None)
         self.g2 = (blk.ls2.gamma.detach().float().contiguous()
                    if isinstance(blk.ls2, LayerScale) else None)
-
-
-def hip_block_forward(x, w, B, T):
-    """One pre-norm block on the fp32 residual stream x [B*T, d] (in place)."""
-    h = vit_ops.layernorm(x, *w.n1)
-    qkv = vit_ops.linear(h, w.w_qkv, w.b_qkv)
-    o = vit_ops.attention(qkv.view(B, T, -1), w.heads)
-    vit_ops.linear_residual_(x, o.view(B * T, -1), w.w_proj, w.b_proj, w.g1)
-    h = vit_ops.layernorm(x, *w.n2)
-    u = vit_ops.linear(h, w.w_fc1, w.b_fc1, vit_ops.EPI_GELU)
-    vit_ops.linear_residual_(x, u, w.w_fc2, w.b_fc2, w.g2)
-    return x
+        # the same tensors behind one native call per block (veon_vit_block)
+        self.packed = vit_ops.BlockWeights(
+            self.heads, self.n1, self.w_qkv, self.b_qkv, self.w_proj, self.b_proj,
+            self.g1, self.n2, self.w_fc1, self.b_fc1, self.w_fc2, self.b_fc2,
+            self.g2, vit_ops.EPI_GELU)
 
 
 class DinoVisionTransformer(nn.Module):
@@ -300,8 +293,10 @@ class DinoVisionTransformer(nn.Module):
                 self._hip_weights = [_HipBlockWeights(b) for b in self.blocks]
             B, T, d = x.shape
             s = x.float().contiguous().view(B * T, d).clone()
+            ws = vit_ops.block_workspace(B, T, d, self._hip_weights[0].packed.mlp_dim,
+                                         x.device)
             for i, w in enumerate(self._hip_weights):
-                hip_block_forward(s, w, B, T)
+                vit_ops.block_forward_(s, w.packed, B, T, ws)
                 if i in taps:
                     outs.append(s.view(B, T, d).clone())
             return outs, s.view(B, T, d)

@@ -125,19 +125,10 @@ class _HipClipWeights:
         self.n2 = (blk.ln_2.weight.detach().float().contiguous(),
                    blk.ln_2.bias.detach().float().contiguous(), blk.ln_2.eps)
         self.act = vit_ops.EPI_QUICKGELU if blk.quick_gelu else vit_ops.EPI_GELU
-
-
-def hip_clip_block(x, w, B, T, bias=None):
-    """One block on the fp32 stream x [B*T, d] (batch-major), in place.
-    bias: optional fp32 [B|1, H|1, T, T] additive logits."""
-    h = vit_ops.layernorm(x, *w.n1)
-    qkv = vit_ops.linear(h, w.w_qkv, w.b_qkv)
-    o = vit_ops.attention(qkv.view(B, T, -1), w.heads, bias)
-    vit_ops.linear_residual_(x, o.view(B * T, -1), w.w_proj, w.b_proj, None)
-    h = vit_ops.layernorm(x, *w.n2)
-    u = vit_ops.linear(h, w.w_fc1, w.b_fc1, w.act)
-    vit_ops.linear_residual_(x, u, w.w_fc2, w.b_fc2, None)
-    return x
+        self.packed = vit_ops.BlockWeights(
+            self.heads, self.n1, self.w_qkv, self.b_qkv, self.w_proj, self.b_proj,
+            None, self.n2, self.w_fc1, self.b_fc1, self.w_fc2, self.b_fc2, None,
+            self.act)
 
 
 def run_blocks(blocks, x_lnd, attn_masks=None, cache=None):
@@ -166,6 +157,7 @@ def run_blocks(blocks, x_lnd, attn_masks=None, cache=None):
     s = torch.empty((N, L, D), dtype=torch.float32, device=x_lnd.device)
     s.copy_(x_lnd.permute(1, 0, 2))
     s = s.view(N * L, D)
+    ws = None
     for i, blk in enumerate(blocks):
         w = cache.get(id(blk))
         if w is None:
@@ -178,7 +170,9 @@ def run_blocks(blocks, x_lnd, attn_masks=None, cache=None):
             elif m.dim() == 3:
                 m = m.view(N, -1, L, L)
             m = m.contiguous()
-        hip_clip_block(s, w, N, L, m)
+        if ws is None:
+            ws = vit_ops.block_workspace(N, L, D, w.packed.mlp_dim, s.device)
+        vit_ops.block_forward_(s, w.packed, N, L, ws, m)
         outs.append(s.view(N, L, D).permute(1, 0, 2).contiguous())
     return outs
 
@@ -203,24 +197,51 @@ class ClipVisualTrunk(nn.Module):
             [ResidualAttentionBlock(width, heads, mlp_ratio, quick_gelu)
              for _ in range(layers)])
         self._hip_cache = {}
+        self._pos_cache = {}
 
     def train(self, mode=True):
         self._hip_cache = {}
+        self._pos_cache = {}
         return super().train(mode)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self._hip_cache = {}
+        self._pos_cache = {}
+        return super()._load_from_state_dict(*args, **kwargs)
 
     def _pos_embed(self, h, w):
         pe = self.positional_embedding
         if (h, w) == self.grid_size:
             return pe
+        inference = not (self.training or torch.is_grad_enabled())
+        key = (h, w, pe.device, pe.dtype)
+        if inference and key in self._pos_cache:
+            return self._pos_cache[key]
         cls, grid = pe[:1], pe[1:]
         grid = grid.reshape(1, self.grid_size[0], self.grid_size[1], -1).permute(0, 3, 1, 2)
         grid = F.interpolate(grid, size=(h, w), mode='bicubic', align_corners=False)
-        return torch.cat([cls, grid.permute(0, 2, 3, 1).reshape(h * w, -1)], 0)
+        out = torch.cat([cls, grid.permute(0, 2, 3, 1).reshape(h * w, -1)], 0)
+        if inference:  # the resize costs more than a block at these sizes
+            self._pos_cache[key] = out
+        return out
+
+    def _patchify(self, x):
+        """conv1 (kernel = stride = patch): at inference the non-overlapping
+        patches are gathered and multiplied as one GEMM -- the same sums without
+        a convolution library call."""
+        p = self.patch_size
+        N, C, H, W = x.shape
+        if (self.training or torch.is_grad_enabled() or H % p or W % p):
+            x = self.conv1(x)
+            _, _, h, w = x.shape
+            return x.flatten(2).permute(0, 2, 1), (h, w)
+        h, w = H // p, W // p
+        cols = x.view(N, C, h, p, w, p).permute(0, 2, 4, 1, 3, 5).reshape(N * h * w, C * p * p)
+        out = cols @ self.conv1.weight.view(self.conv1.out_channels, -1).t()
+        return out.view(N, h * w, -1), (h, w)
 
     def tokens(self, x):
-        x = self.conv1(x)
-        _, _, h, w = x.shape
-        x = x.flatten(2).permute(0, 2, 1)
+        x, (h, w) = self._patchify(x)
         cls = self.class_embedding.to(x.dtype).expand(x.shape[0], 1, -1)
         x = torch.cat([cls, x], dim=1) + self._pos_embed(h, w).to(x.dtype)
         return self.ln_pre(x).permute(1, 0, 2), (h, w)     # LND

@@ -4,6 +4,8 @@ bf16 tensors are ordinary ``torch.bfloat16`` tensors; the residual stream and
 all vectors (bias, LayerNorm / LayerScale parameters) are fp32.  Everything
 launches on the current stream; there is no CPU path.
 """
+import ctypes
+
 import torch
 
 from . import _lib
@@ -103,3 +105,50 @@ def attention(qkv, num_heads, bias=None, out=None):
             _lib.stream_ptr(dev))
     _lib.check(st, 'veon_vit_attention')
     return out
+
+
+class BlockWeights:
+    """Device weights of one transformer block packed for ``veon_vit_block``
+    (include/veon_hip.h): keeps the tensors alive and the C struct ready."""
+
+    def __init__(self, heads, n1, w_qkv, b_qkv, w_proj, b_proj, g1, n2, w_fc1,
+                 b_fc1, w_fc2, b_fc2, g2, act):
+        self.heads = heads
+        self.keep = (n1[0], n1[1], w_qkv, b_qkv, w_proj, b_proj, g1, n2[0], n2[1],
+                     w_fc1, b_fc1, w_fc2, b_fc2, g2)
+        for t in self.keep:
+            assert t is None or (t.is_cuda and t.is_contiguous())
+        self.d = w_qkv.shape[1]
+        self.mlp_dim = w_fc1.shape[0]
+        p = _lib.ptr
+        self.c = _lib.VitBlockWeights(
+            p(n1[0]).value, p(n1[1]).value, p(w_qkv).value, p(b_qkv).value,
+            p(w_proj).value, p(b_proj).value, p(g1).value, p(n2[0]).value,
+            p(n2[1]).value, p(w_fc1).value, p(b_fc1).value, p(w_fc2).value,
+            p(b_fc2).value, p(g2).value, float(n1[2]), float(n2[2]),
+            int(self.mlp_dim), int(act))
+
+
+def block_workspace(B, T, d, mlp_dim, device):
+    n = _lib.lib().veon_vit_block_workspace_bytes(B, T, d, mlp_dim)
+    return torch.empty(n, dtype=torch.uint8, device=device)
+
+
+def block_forward_(x, w, B, T, ws, bias=None):
+    """One pre-norm block on the fp32 residual stream x [B*T, d], in place, as a
+    single native call (seven launches)."""
+    dev = _dev(x, ws)
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.shape == (B * T, w.d)
+    sb = sh = 0
+    if bias is not None:
+        assert bias.dtype == torch.float32 and bias.dim() == 4
+        assert bias.shape[-2:] == (T, T) and bias.stride(-1) == 1 \
+            and bias.stride(-2) == T
+        sb = bias.stride(0) if bias.shape[0] > 1 else 0
+        sh = bias.stride(1) if bias.shape[1] > 1 else 0
+    with torch.cuda.device(dev):
+        st = _lib.lib().veon_vit_block(
+            _lib.ptr(x), ctypes.byref(w.c), _lib.ptr(bias), sb, sh, _lib.ptr(ws),
+            ws.numel(), B, T, w.d, w.heads, _lib.stream_ptr(dev))
+    _lib.check(st, 'veon_vit_block')
+    return x
