@@ -26,21 +26,30 @@
 
 namespace {
 
-constexpr int CBN = 128, CBK = 64;
-constexpr int CW_ELEMS = CBN * CBK;
+constexpr int CBK = 64;
 
-template <int MT, bool RELU, bool RESID>
-__global__ __launch_bounds__(256) void k_conv3d_k3(
+// Tile = (WM*16*MT) voxels x (64*WN) features, WM x WN waves of (16*MT) x 64 each.
+template <int WM, int WN, int MT, bool RELU, bool RESID>
+__global__ __launch_bounds__(64 * WM * WN) void k_conv3d_k3(
     const bf16_t* __restrict__ in, const bf16_t* __restrict__ W,
     const float* __restrict__ scale, const float* __restrict__ shift,
     const bf16_t* __restrict__ resid, bf16_t* __restrict__ out, int planes,
     int Zp, int Yp, int Xp, int Cin, int Cout) {
-  constexpr int BM = 32 * MT;
+  constexpr int BM = WM * 16 * MT;
+  constexpr int CBN = 64 * WN;
+  constexpr int NW = WM * WN;              // waves
+  constexpr int NT = 64 * NW;              // threads
+  // DMA pieces (8 rows = 1 KiB each) are dealt round-robin to the waves:
+  // wave w issues pieces w, w + NW, ... of each slab
+  constexpr int APIECES = BM / 8, WPIECES = CBN / 8;
+  constexpr int AP = (APIECES + NW - 1) / NW;  // per wave, last may be absent
+  constexpr int WP = (WPIECES + NW - 1) / NW;
   constexpr int A_ELEMS = BM * CBK;
+  constexpr int CW_ELEMS = CBN * CBK;
   constexpr int BUF_ELEMS = A_ELEMS + CW_ELEMS;
   extern __shared__ __attribute__((aligned(16))) bf16_t smem[];  // [2][A|W]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
   const int fr = lane & 15, fg = lane >> 4;
   const int YX = Yp * Xp;
   const int M = planes * YX;  // planes = B * Zp
@@ -55,9 +64,10 @@ __global__ __launch_bounds__(256) void k_conv3d_k3(
     const int z0 = p0 % Zp, z1 = p1 % Zp;
     const bool h0 = z0 == 0 || z0 == Zp - 1, h1 = z1 == 0 || z1 == Zp - 1;
     if (h0 && h1 && p1 - p0 <= 1) {
-      // BM rows x 128 features of bf16 = BM*256 bytes, 16 bytes per lane-store
-      for (int i = tid; i < BM * 16; i += 256) {
-        const int r = i >> 4, c8 = (i & 15) * 8;
+      // BM rows x CBN features of bf16, 16 bytes per lane-store
+      constexpr int CPR = CBN / 8;  // 16-byte chunks per row
+      for (int i = tid; i < BM * CPR; i += NT) {
+        const int r = i / CPR, c8 = (i % CPR) * 8;
         if (m0 + r < M && n0 + c8 < Cout)
           *reinterpret_cast<uint4*>(out + (int64_t)(m0 + r) * Cout + n0 + c8) =
               make_uint4(0u, 0u, 0u, 0u);
@@ -69,17 +79,17 @@ __global__ __launch_bounds__(256) void k_conv3d_k3(
   // DMA map as k_gemm_bf16: a wave instruction fills 8 rows of a slab; lane l
   // lands in row r = 8*piece + l/8, physical chunk l%8, and fetches logical
   // chunk (l%8) ^ (r&7).  Activation rows are NOT clamped (guard rows).
-  const bf16_t* srcA[MT];
-  const bf16_t* srcW[4];
+  const bf16_t* srcA[AP];
+  const bf16_t* srcW[WP];
 #pragma unroll
-  for (int j = 0; j < MT; ++j) {
-    const int r = (wave * MT + j) * 8 + (lane >> 3);
+  for (int j = 0; j < AP; ++j) {
+    const int r = (wave + j * NW) * 8 + (lane >> 3);
     const int c = (lane & 7) ^ (r & 7);
     srcA[j] = in + (int64_t)(m0 + r) * Cin + c * 8;
   }
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int r = (wave * 4 + j) * 8 + (lane >> 3);
+  for (int j = 0; j < WP; ++j) {
+    const int r = (wave + j * NW) * 8 + (lane >> 3);
     const int c = (lane & 7) ^ (r & 7);
     const int gn = n0 + r < Cout ? n0 + r : Cout - 1;
     srcW[j] = W + (int64_t)gn * K + c * 8;
@@ -97,13 +107,15 @@ __global__ __launch_bounds__(256) void k_conv3d_k3(
     bf16_t* dW = dA + A_ELEMS;
     const int64_t ao = a_off(kt);
 #pragma unroll
-    for (int j = 0; j < MT; ++j)
-      __builtin_amdgcn_global_load_lds((gptr_t)(srcA[j] + ao),
-                                       (lptr_t)(dA + (wave * MT + j) * 512), 16, 0, 0);
+    for (int j = 0; j < AP; ++j)
+      if (wave + j * NW < APIECES)  // wave-uniform
+        __builtin_amdgcn_global_load_lds((gptr_t)(srcA[j] + ao),
+                                         (lptr_t)(dA + (wave + j * NW) * 512), 16, 0, 0);
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-      __builtin_amdgcn_global_load_lds((gptr_t)(srcW[j] + kt * CBK),
-                                       (lptr_t)(dW + (wave * 4 + j) * 512), 16, 0, 0);
+    for (int j = 0; j < WP; ++j)
+      if (wave + j * NW < WPIECES)
+        __builtin_amdgcn_global_load_lds((gptr_t)(srcW[j] + kt * CBK),
+                                         (lptr_t)(dW + (wave + j * NW) * 512), 16, 0, 0);
   };
 
   f32x4 acc[MT][4];
@@ -125,11 +137,7 @@ __global__ __launch_bounds__(256) void k_conv3d_k3(
   }
 
   const int nk = 27 * cpk;
-  dma(0, 0);
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nk) dma(buf ^ 1, kt + 1);
+  auto compute = [&](int buf) {
     const bf16_t* tA = smem + buf * BUF_ELEMS;
     const bf16_t* tW = tA + A_ELEMS;
 #pragma unroll
@@ -149,7 +157,14 @@ __global__ __launch_bounds__(256) void k_conv3d_k3(
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i],
                                                                acc[i][j], 0, 0, 0);
     }
-    __syncthreads();
+  };
+  dma(0, 0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) dma(buf ^ 1, kt + 1);
+    compute(buf);
+    __syncthreads();  // next slab landed (vmcnt drained) and this one released
   }
 
   // epilogue: lane owns 4 consecutive features of one voxel per tile
@@ -252,8 +267,8 @@ extern "C" {
 
 int64_t veon_conv3d_guard_rows(int Y, int X) {
   if (Y <= 0 || X <= 0) return 0;
-  // largest tap offset + the overhang of the last 128-row tile
-  return (int64_t)(Y + 2) * (X + 2) + (X + 2) + 1 + 128;
+  // largest tap offset + the overhang of the last (up to 512-row) tile
+  return (int64_t)(Y + 2) * (X + 2) + (X + 2) + 1 + 512;
 }
 
 int veon_conv3d_k3_bf16(const void* in_padded, const void* w_bf16,
@@ -269,37 +284,69 @@ int veon_conv3d_k3_bf16(const void* in_padded, const void* w_bf16,
     return VEON_ERR_BAD_ARG;
   const int64_t M = (int64_t)B * (Z + 2) * (Y + 2) * (X + 2);
   if (M > 0x3fffffffLL) return VEON_ERR_BAD_ARG;
-  const int64_t ncol = (Cout + CBN - 1) / CBN;
-  const int mt = (((M + 63) / 64) * ncol > 8 * kNumCU) ? 4 : 2;
-  const dim3 grid((unsigned)ncol, (unsigned)((M + 32 * mt - 1) / (32 * mt)));
+  // Tile choice.  256 features wide when the layer has them (the activation
+  // slab is then fetched once, not once per 128-feature column); the height is
+  // the candidate with the fewest rounds x rows over the 256 CUs, counting only
+  // the tiles that do work (z-halo planes are skipped).  One workgroup per CU,
+  // 12-16 waves of small per-wave tiles: measured faster than 8 waves of
+  // bigger ones, and a 3-stage counted-vmcnt DMA ring was not faster than this.
+  struct Tile { int wm, wn, mt; };
+  static const Tile wide[] = {{4, 4, 3}, {4, 4, 4}, {3, 4, 7}};   // 192/256/336 x 256
+  static const Tile narrow[] = {{2, 2, 2}, {2, 2, 4}};             // 64/128 x 128
+  const bool is_wide = Cout >= 256;
+  const Tile* cands = is_wide ? wide : narrow;
+  const int ncand = is_wide ? 3 : 2;
+  const int64_t active = (int64_t)B * Z * (Y + 2) * (X + 2);  // rows off the z-halo
+  int wm = cands[0].wm, wn = cands[0].wn, mt = cands[0].mt;
+  int64_t best = -1;
+  for (int i = 0; i < ncand; ++i) {
+    const int64_t rows = cands[i].wm * 16 * cands[i].mt;
+    const int64_t cols = (Cout + 64 * cands[i].wn - 1) / (64 * cands[i].wn);
+    const int64_t tiles = ((active + rows - 1) / rows + B) * cols;  // + straddlers
+    const int64_t slots = is_wide ? kNumCU : 2 * kNumCU;  // resident workgroups
+    const int64_t cost = ((tiles + slots - 1) / slots) * rows;
+    if (best < 0 || cost < best) {
+      best = cost;
+      wm = cands[i].wm; wn = cands[i].wn; mt = cands[i].mt;
+    }
+  }
+  const int bm = wm * 16 * mt;
+  const int64_t ncol = (Cout + 64 * wn - 1) / (64 * wn);
+  const dim3 grid((unsigned)ncol, (unsigned)((M + bm - 1) / bm));
   hipStream_t s = static_cast<hipStream_t>(stream);
   const bf16_t* I = static_cast<const bf16_t*>(in_padded);
   const bf16_t* Wt = static_cast<const bf16_t*>(w_bf16);
   const bf16_t* R = static_cast<const bf16_t*>(resid_padded);
   bf16_t* O = static_cast<bf16_t*>(out_padded);
   const int planes = B * (Z + 2);
-#define VEON_LAUNCH_CONV(MT, RELU, RESID)                                      \
+#define VEON_LAUNCH_CONV(WM, WN, MT, RELU, RESID)                              \
   do {                                                                         \
-    constexpr int lds = 2 * (32 * MT * CBK + CW_ELEMS) * (int)sizeof(bf16_t);  \
+    constexpr int lds =                                                        \
+        2 * (WM * 16 * MT + 64 * WN) * CBK * (int)sizeof(bf16_t);              \
     static const hipError_t attr = hipFuncSetAttribute(                        \
-        reinterpret_cast<const void*>(&k_conv3d_k3<MT, RELU, RESID>),          \
+        reinterpret_cast<const void*>(&k_conv3d_k3<WM, WN, MT, RELU, RESID>),  \
         hipFuncAttributeMaxDynamicSharedMemorySize, lds);                      \
     if (attr != hipSuccess) return VEON_ERR_LAUNCH;                            \
-    hipLaunchKernelGGL((k_conv3d_k3<MT, RELU, RESID>), grid, dim3(256), lds, s, \
-                       I, Wt, scale, shift, R, O, planes, Z + 2, Y + 2, X + 2, \
-                       Cin, Cout);                                             \
+    hipLaunchKernelGGL((k_conv3d_k3<WM, WN, MT, RELU, RESID>), grid,           \
+                       dim3(64 * WM * WN), lds, s, I, Wt, scale, shift, R, O,  \
+                       planes, Z + 2, Y + 2, X + 2, Cin, Cout);                \
   } while (0)
-#define VEON_LAUNCH_CONV_MT(RELU, RESID)                                       \
+#define VEON_TILE_IS(a, b, c) (wm == a && wn == b && mt == c)
+#define VEON_LAUNCH_CONV_T(RELU, RESID)                                        \
   do {                                                                         \
-    if (mt == 4) VEON_LAUNCH_CONV(4, RELU, RESID);                             \
-    else VEON_LAUNCH_CONV(2, RELU, RESID);                                     \
+    if (VEON_TILE_IS(3, 4, 7)) VEON_LAUNCH_CONV(3, 4, 7, RELU, RESID);         \
+    else if (VEON_TILE_IS(4, 4, 3)) VEON_LAUNCH_CONV(4, 4, 3, RELU, RESID);    \
+    else if (VEON_TILE_IS(4, 4, 4)) VEON_LAUNCH_CONV(4, 4, 4, RELU, RESID);    \
+    else if (VEON_TILE_IS(2, 2, 4)) VEON_LAUNCH_CONV(2, 2, 4, RELU, RESID);    \
+    else VEON_LAUNCH_CONV(2, 2, 2, RELU, RESID);                               \
   } while (0)
   if (relu) {
-    if (R) VEON_LAUNCH_CONV_MT(true, true); else VEON_LAUNCH_CONV_MT(true, false);
+    if (R) VEON_LAUNCH_CONV_T(true, true); else VEON_LAUNCH_CONV_T(true, false);
   } else {
-    if (R) VEON_LAUNCH_CONV_MT(false, true); else VEON_LAUNCH_CONV_MT(false, false);
+    if (R) VEON_LAUNCH_CONV_T(false, true); else VEON_LAUNCH_CONV_T(false, false);
   }
-#undef VEON_LAUNCH_CONV_MT
+#undef VEON_LAUNCH_CONV_T
+#undef VEON_TILE_IS
 #undef VEON_LAUNCH_CONV
   return launch_status();
 }
