@@ -256,6 +256,10 @@ int veon_two_hot_depth(int BN, int H, int W, int ds, int D, float lo, float step
  *                      2: QuickGELU x*sigmoid(1.702x) -> bf16 out;
  *                      3: resid[M,N] (fp32, in place) += gamma[N] * C
  *                         (gamma NULL = 1): LayerScale + residual add.
+ *                      4: A.W^T * gamma[N] + bias[N] -> bf16 out (a 1x1x1
+ *                         convolution + eval-mode BatchNorm);  5: the same + ReLU
+ *                         (the ConvModules of PredHead3DOcc / PredHead3DSem,
+ *                         align_net_occ3d.py:431-534).
  * veon_vit_attention : qkv bf16 [B,T,3,H,64] (q pre-scaled) -> out bf16
  *                      [B,T,H*64] = softmax(q k^T + bias) v, flash style.
  *                      bias (optional) fp32 [.,.,T,T] with batch / head strides

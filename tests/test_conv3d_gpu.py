@@ -121,3 +121,38 @@ def test_training_and_cpu_take_the_torch_definition():
     blk = ResBlock3D(64, 64)
     y = blk(torch.randn(1, 64, 2, 3, 3))
     assert y.shape == (1, 64, 2, 3, 3) and y.requires_grad
+
+
+def test_prediction_heads_match_module_definition():
+    """PredHead3DOcc / PredHead3DSem: the 1x1x1 ConvModule chains as GEMMs with
+    the BN fold and ReLU in the epilogue, fed straight from the body's padded
+    volume, vs the PyTorch definition on the body's fp32 output."""
+    from veon_amd.models.semantic_net import PredHead3DOcc, PredHead3DSem
+    torch.manual_seed(11)
+    body = AlignBody3D(embed_dim=256, layer_depth=1)
+    occ, sem = PredHead3DOcc(256, 2), PredHead3DSem(256, 96)
+    for mod in (body, occ, sem):
+        for m in mod.modules():
+            if isinstance(m, torch.nn.BatchNorm3d):
+                m.running_mean.normal_(0, 0.2)
+                m.running_var.uniform_(0.5, 1.5)
+                m.weight.data.uniform_(0.5, 1.5)
+                m.bias.data.normal_(0, 0.2)
+            if isinstance(m, torch.nn.Conv3d):
+                m.weight.data = _bf(m.weight.data)
+        mod.to(DEV).eval()
+    x = _bf(torch.randn(2, 256, 3, 9, 10)).to(DEV)
+    before = dict(_lib.CALLS)
+    with torch.no_grad():
+        vol = body(x, return_volume=True)
+        assert isinstance(vol, conv3d_ops.PaddedVolume)
+        got_occ, got_sem = occ(vol), sem(vol)
+        feat = conv3d_ops.unpack(vol)       # what the heads saw, as fp32
+        occ_cpu, sem_cpu = occ.cpu(), sem.cpu()
+        want_occ, want_sem = occ_cpu(feat.cpu()), sem_cpu(feat.cpu())
+    assert _lib.CALLS['veon_vit_gemm'] - before.get('veon_vit_gemm', 0) == 5
+    assert got_occ.shape == (2, 2, 3, 9, 10) and got_sem.shape == (2, 96, 3, 9, 10)
+    for got, want in ((got_occ, want_occ), (got_sem, want_sem)):
+        rel = ((got.cpu() - want).norm() / want.norm()).item()
+        assert rel < 1.5e-2, rel   # bf16 intermediates between the convs
+    assert float(got_sem.abs().max()) <= 0.5

@@ -9,7 +9,8 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from veon_amd import conv3d_ops  # noqa: E402
-from veon_amd.models.semantic_net import AlignBody3D  # noqa: E402
+from veon_amd.models.semantic_net import (AlignBody3D, PredHead3DOcc,  # noqa: E402
+                                          PredHead3DSem)
 from tools.vit_bench import timeit, PEAK  # noqa: E402
 
 
@@ -35,6 +36,14 @@ def main():
         us = timeit(lambda: body(x), iters=10)
         print('AlignBody3D 4 blocks     %8.1f us  %6.1f TF/s (%4.1f%%)  -> %.1f samples/s' % (
             us, 8 * fl / us / 1e6, 100 * 8 * fl / us / 1e6 / PEAK, 1e6 / us))
+        occ = PredHead3DOcc(C, 2).to(dev).eval()
+        sem = PredHead3DSem(C, 768).to(dev).eval()
+
+        def body_heads():
+            vol = body(x, return_volume=True)
+            return occ(vol), sem(vol)
+        us2 = timeit(body_heads, iters=10)
+        print('body + occ/sem heads     %8.1f us  (heads %.1f us: 5 GEMMs on the padded rows + 2 unpacks)' % (us2, us2 - us))
         if '--torch' in sys.argv:
             body.use_hip = False
             print('torch fp32 eager body    %8.1f us' % timeit(lambda: body(x), iters=3))

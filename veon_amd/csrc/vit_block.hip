@@ -82,7 +82,8 @@ __global__ __launch_bounds__(256) void k_layernorm(
 constexpr int BN = 128, BK = 64;
 constexpr int W_ELEMS = BN * BK;  // weight slab per buffer (16 KiB)
 
-enum { EPI_BF16 = 0, EPI_GELU = 1, EPI_QUICKGELU = 2, EPI_RESID = 3 };
+enum { EPI_BF16 = 0, EPI_GELU = 1, EPI_QUICKGELU = 2, EPI_RESID = 3,
+       EPI_AFFINE = 4, EPI_AFFINE_RELU = 5 };
 
 // erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below the bf16
 // rounding of the output): one rcp, one exp, five FMAs instead of libm's erff.
@@ -212,6 +213,13 @@ __global__ __launch_bounds__(256) void k_gemm_bf16(
       const int n = n0 + wn * 64 + j * 16 + fg * 4;
       if (n >= N) continue;
       float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      if (EPI == EPI_AFFINE || EPI == EPI_AFFINE_RELU) {
+        // C*gamma + bias: a folded eval-mode BatchNorm after a 1x1 convolution
+        if (gamma != nullptr) {
+          const float4 g4 = *reinterpret_cast<const float4*>(gamma + n);
+          v[0] *= g4.x; v[1] *= g4.y; v[2] *= g4.z; v[3] *= g4.w;
+        }
+      }
       if (bias != nullptr) {
         const float4 b4 = *reinterpret_cast<const float4*>(bias + n);
         v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
@@ -230,6 +238,7 @@ __global__ __launch_bounds__(256) void k_gemm_bf16(
         for (int k = 0; k < 4; ++k) {
           if (EPI == EPI_GELU) v[k] = gelu_erf(v[k]);
           if (EPI == EPI_QUICKGELU) v[k] = quick_gelu(v[k]);
+          if (EPI == EPI_AFFINE_RELU) v[k] = fmaxf(v[k], 0.f);
         }
         bf16x4 o;
         o[0] = (short)f2bf(v[0]); o[1] = (short)f2bf(v[1]);
@@ -550,6 +559,8 @@ int veon_vit_gemm(const void* a_bf16, const void* w_bf16, const float* bias,
     case EPI_GELU: VEON_LAUNCH_GEMM_MT(EPI_GELU); break;
     case EPI_QUICKGELU: VEON_LAUNCH_GEMM_MT(EPI_QUICKGELU); break;
     case EPI_RESID: VEON_LAUNCH_GEMM_MT(EPI_RESID); break;
+    case EPI_AFFINE: VEON_LAUNCH_GEMM_MT(EPI_AFFINE); break;
+    case EPI_AFFINE_RELU: VEON_LAUNCH_GEMM_MT(EPI_AFFINE_RELU); break;
     default: return VEON_ERR_BAD_ARG;
   }
 #undef VEON_LAUNCH_GEMM_MT

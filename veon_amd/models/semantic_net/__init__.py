@@ -1,5 +1,6 @@
-from .align_net_body import AlignBody3D, ConvModule3d, ResBlock3D
+from .align_net_body import (AlignBody3D, ConvModule3d, PredHead3DOcc,
+                             PredHead3DSem, ResBlock3D)
 from .clip_blocks import ClipVisualTrunk, ResidualAttentionBlock
 
 __all__ = ['ResidualAttentionBlock', 'ClipVisualTrunk', 'ResBlock3D',
-           'ConvModule3d', 'AlignBody3D']
+           'ConvModule3d', 'AlignBody3D', 'PredHead3DOcc', 'PredHead3DSem']

@@ -19,7 +19,7 @@ take the plain PyTorch formulation (the definition of the module).
 import torch
 import torch.nn as nn
 
-from ... import conv3d_ops
+from ... import conv3d_ops, vit_ops
 
 
 class ConvModule3d(nn.Module):
@@ -40,9 +40,9 @@ class ConvModule3d(nn.Module):
             x = self.activate(x)
         return x
 
-    def folded(self):
+    def folded(self, pack=True):
         """(packed bf16 weight, fp32 scale, fp32 shift) of conv + eval-mode BN."""
-        w = conv3d_ops.pack_weight(self.conv.weight)
+        w = conv3d_ops.pack_weight(self.conv.weight) if pack else None
         cout = self.conv.out_channels
         dev = self.conv.weight.device
         scale = torch.ones(cout, device=dev)
@@ -55,6 +55,112 @@ class ConvModule3d(nn.Module):
         if self.conv.bias is not None:
             shift = shift + self.conv.bias.detach().float() * scale
         return w, scale.contiguous(), shift.contiguous()
+
+
+def _pointwise(vol, cm, out_channels=None):
+    """1x1x1 ConvModule3d on a PaddedVolume as one GEMM over its rows (the halo
+    rows get the bias/shift -- they are never unpacked)."""
+    if '_hip' not in cm.__dict__ or cm.__dict__['_hip'] is None:
+        conv = cm.conv
+        cout = conv.out_channels
+        npad = (cout + 7) // 8 * 8       # the GEMM wants N % 4 == 0, rows 16-B
+        w = torch.zeros(npad, conv.in_channels, device=conv.weight.device)
+        w[:cout] = conv.weight.detach().float().view(cout, -1)
+        _, scale, shift = cm.folded(pack=False)
+        sc = torch.ones(npad, device=w.device)
+        sh = torch.zeros(npad, device=w.device)
+        sc[:cout], sh[:cout] = scale, shift
+        cm.__dict__['_hip'] = (w.to(torch.bfloat16).contiguous(), sc, sh, npad)
+    w, sc, sh, npad = cm.__dict__['_hip']
+    B, C, Z, Y, X = vol.shape
+    key = (B, npad, Z, Y, X, str(vol.device))
+    bufs = cm.__dict__.setdefault('_hip_out', {})
+    if key not in bufs:  # reused across calls: the result is consumed at once
+        bufs[key] = conv3d_ops.PaddedVolume(B, npad, Z, Y, X, vol.device)
+    out = bufs[key]
+    epi = vit_ops.EPI_AFFINE_RELU if cm.activate is not None else vit_ops.EPI_AFFINE
+    vit_ops.linear(vol.rows, w, sh, epi, out=out.rows, gamma=sc)
+    return out
+
+
+class _PredHead3D(nn.Module):
+    """Shared machinery of the two prediction heads: a chain of 1x1x1
+    ConvModules.  On a PaddedVolume (or a ROCm fp32 volume at inference) the
+    chain runs as GEMMs on the channels-last rows."""
+
+    _names = ()
+
+    def _chain(self):
+        return [getattr(self, n) for n in self._names]
+
+    def train(self, mode=True):
+        for cm in self._chain():
+            cm.__dict__['_hip'] = None
+        return super().train(mode)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        for cm in self._chain():
+            cm.__dict__['_hip'] = None
+        return super()._load_from_state_dict(*args, **kwargs)
+
+    def _hip_ok(self, x):
+        if not all(cm.conv.in_channels % 64 == 0 for cm in self._chain()):
+            return False
+        if isinstance(x, conv3d_ops.PaddedVolume):
+            return True
+        return x.is_cuda and not self.training and not torch.is_grad_enabled()
+
+    def _run(self, x):
+        if not self._hip_ok(x):
+            if isinstance(x, conv3d_ops.PaddedVolume):
+                x = conv3d_ops.unpack(x)
+            for cm in self._chain():
+                x = cm(x)
+            return x
+        vol = x if isinstance(x, conv3d_ops.PaddedVolume) else conv3d_ops.pack(x)
+        for cm in self._chain():
+            vol = _pointwise(vol, cm)
+        out = conv3d_ops.unpack(vol)
+        return out[:, :self._chain()[-1].conv.out_channels]
+
+
+class PredHead3DOcc(_PredHead3D):
+    """Binary occupancy head (align_net_occ3d.py:431-470): 1x1x1 conv C -> C/4,
+    BN, ReLU; 1x1x1 conv C/4 -> channels_out."""
+
+    _names = ('occ_conv1', 'occ_conv2')
+
+    def __init__(self, channels_in, channels_out, stride=1, use_checkpoint=False):
+        super().__init__()
+        mid = channels_in // 4
+        self.occ_conv1 = ConvModule3d(channels_in, mid, 1, stride, 0, bias=False,
+                                      norm=True, act=True)
+        self.occ_conv2 = ConvModule3d(mid, channels_out, 1, stride, 0, bias=False,
+                                      norm=False, act=False)
+        self.use_checkpoint = use_checkpoint
+
+    def forward(self, x):
+        return self._run(x)
+
+
+class PredHead3DSem(_PredHead3D):
+    """Feature head (align_net_occ3d.py:473-534): three 1x1x1 convs (BN+ReLU
+    after the first two, the first with a conv bias), then sigmoid - 0.5."""
+
+    _names = ('occ_conv1', 'occ_conv2', 'occ_conv3')
+
+    def __init__(self, channels_in, channels_out, stride=1, use_checkpoint=False):
+        super().__init__()
+        self.occ_conv1 = ConvModule3d(channels_in, channels_in, 1, stride, 0,
+                                      bias=True, norm=True, act=True)
+        self.occ_conv2 = ConvModule3d(channels_in, channels_in, 1, stride, 0,
+                                      bias=False, norm=True, act=True)
+        self.occ_conv3 = ConvModule3d(channels_in, channels_out, 1, stride, 0,
+                                      bias=False, norm=False, act=False)
+        self.use_checkpoint = use_checkpoint
+
+    def forward(self, x):
+        return self._run(x).sigmoid() - 0.5
 
 
 class ResBlock3D(nn.Module):
@@ -121,7 +227,9 @@ class AlignBody3D(nn.Module):
                                for _ in range(3)]
         return self._bufs[key]
 
-    def forward(self, x, start=0, stop=None):
+    def forward(self, x, start=0, stop=None, return_volume=False):
+        """``return_volume``: hand the result over as the PaddedVolume the
+        prediction heads consume directly (no unpack / re-pack)."""
         blocks = list(self.layers_3d_body)[start:stop]
         if not self._use_hip(x):
             for blk in blocks:
@@ -137,4 +245,4 @@ class AlignBody3D(nn.Module):
             conv3d_ops.conv3d_k3(a, w1, s1, b1, relu=True, out=t)
             conv3d_ops.conv3d_k3(t, w2, s2, b2, resid=a, relu=True, out=o)
             a, o = o, a
-        return conv3d_ops.unpack(a)
+        return a if return_volume else conv3d_ops.unpack(a)

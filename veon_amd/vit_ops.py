@@ -11,6 +11,7 @@ import torch
 from . import _lib
 
 EPI_BF16, EPI_GELU, EPI_QUICKGELU, EPI_RESID = 0, 1, 2, 3
+EPI_AFFINE, EPI_AFFINE_RELU = 4, 5
 
 
 def _dev(*ts):
@@ -45,8 +46,9 @@ def layernorm(x, weight, bias, eps=1e-6, out=None):
     return out
 
 
-def linear(a, w, bias=None, epilogue=EPI_BF16, out=None):
-    """a bf16 [M,K], w bf16 [N,K] (nn.Linear layout) -> bf16 [M,N]."""
+def linear(a, w, bias=None, epilogue=EPI_BF16, out=None, gamma=None):
+    """a bf16 [M,K], w bf16 [N,K] (nn.Linear layout) -> bf16 [M,N].  ``gamma``
+    (fp32 [N]) is the per-feature scale of the EPI_AFFINE* epilogues."""
     dev = _dev(a, w)
     assert a.dtype == torch.bfloat16 and w.dtype == torch.bfloat16
     assert a.is_contiguous() and w.is_contiguous()
@@ -58,7 +60,7 @@ def linear(a, w, bias=None, epilogue=EPI_BF16, out=None):
         out = torch.empty(a.shape[:-1] + (N,), dtype=torch.bfloat16, device=dev)
     with torch.cuda.device(dev):
         st = _lib.lib().veon_vit_gemm(
-            _lib.ptr(a), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(None),
+            _lib.ptr(a), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(gamma),
             _lib.ptr(None), _lib.ptr(out), M, N, K, epilogue,
             _lib.stream_ptr(dev))
     _lib.check(st, 'veon_vit_gemm')
