@@ -277,6 +277,24 @@ int veon_vit_attention(const void *qkv_bf16, const float *bias,
                        void *stream);
 
 /*
+ * The fused pool + max-pool writing straight into the Conv3d body's input: the
+ * interior of the zero-padded channels-last bf16 grid [B][Z/dz+2][Y/dy+2][X/dx+2][C]
+ * (see veon_conv3d_k3_bf16; allocate it zeroed once, the halo is never
+ * written).  Values are the fp32 results of veon_bev_pool_v2_fwd_maxpool_ex
+ * rounded to bf16 -- what veon_volume_pack_bf16 of that tensor would store.
+ */
+int veon_bev_pool_v2_fwd_maxpool_padded(int c, int n_intervals, int batch, int Z,
+                                        int Y, int X, int dz, int dy, int dx,
+                                        const float *depth, const void *feat,
+                                        int feat_dtype, const int *ranks_depth,
+                                        const int *ranks_feat,
+                                        const int *ranks_bev,
+                                        const int *interval_starts,
+                                        const int *interval_lengths,
+                                        const int *row_first,
+                                        void *out_padded_bf16, void *stream);
+
+/*
  * One whole pre-norm transformer block on the fp32 residual stream x [B*T, d]
  * (in place): x += g1*(proj(attn(LN1(x)))), x += g2*(fc2(act(fc1(LN2(x))))) --
  * the DINOv2 block (dinov2_layers/block.py:85-110; g = LayerScale) and the CLIP

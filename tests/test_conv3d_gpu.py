@@ -156,3 +156,37 @@ def test_prediction_heads_match_module_definition():
         rel = ((got.cpu() - want).norm() / want.norm()).item()
         assert rel < 1.5e-2, rel   # bf16 intermediates between the convs
     assert float(got_sem.abs().max()) <= 0.5
+
+
+def test_lift_writes_the_body_input_directly():
+    """LSSViewTransformerRaw.forward(out_volume=...) + AlignBody3D on that
+    volume == pack(lift output) + body, bit for bit, and the lift's volume is
+    left intact by the body."""
+    from veon_amd import synthetic
+    from veon_amd.models import build_neck
+    size, C = (128, 352), 64
+    vt = build_neck(dict(type='LSSViewTransformerRaw', grid_config=synthetic.GRID_VEON,
+                         input_size=size, out_channels=C, collapse_z=False,
+                         ds_feat=[2, 2, 2])).to(DEV).eval()
+    geom = [t.to(DEV) for t in synthetic.rig_inputs(synthetic.make_rig(1, 6, size))]
+    depth, feat = synthetic.make_depth_feat(1, 6, vt.D, C, size[0] // 16, size[1] // 16, 0)
+    depth, feat = depth.to(DEV), feat.to(DEV)
+    for sync_free in (False, True):
+        vt.sync_free = sync_free
+        with torch.no_grad():
+            ref = vt([feat] + geom, depth)                     # (B,C,Zo,Yo,Xo) fp32
+            assert ref.shape == (1, C, 8, 100, 100) and float(ref.abs().sum()) > 0
+            vol = conv3d_ops.PaddedVolume(*ref.shape, DEV)
+            got = vt([feat] + geom, depth, out_volume=vol)
+            assert got is vol
+            assert torch.equal(conv3d_ops.unpack(vol), _bf(ref))
+    with torch.no_grad():
+        body = AlignBody3D(embed_dim=C, layer_depth=2).to(DEV).eval()
+        keep = vol.rows.clone()
+        a = body(vol)
+        b = body(ref)
+        assert torch.equal(a, b)
+        assert torch.equal(vol.rows, keep)
+        # chaining partial ranges through volumes
+        c = body(body(vol, 0, 1, return_volume=True), 1, 2)
+        assert torch.equal(a, c)

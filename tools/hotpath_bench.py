@@ -6,10 +6,11 @@ random weights):
   DepthAnythingV2 (MFMA encoder, hipGraph | DPT head on PyTorch/MIOpen)
     -> metric depth -> fused block-min + two-hot depth
   CLIP ViT-B/16 trunk (MFMA) -> stand-in 1x1 projection to C=256 at Hf x Wf
-  -> sync-free lift with the fused 2x2x2 max-pool
-  -> AlignNetOcc3D Conv3d body, 4 ResBlock3D on MFMA
+  -> sync-free lift with the fused 2x2x2 max-pool, written straight into
+  -> the AlignNetOcc3D Conv3d body's padded bf16 input, 4 ResBlock3D on MFMA
+  -> PredHead3DOcc / PredHead3DSem (1x1x1 convs as GEMMs on the padded rows)
 
-The SAN side adapter, HSA network, prediction heads and the classifier einsum
+The SAN side adapter, HSA network, trilinear upsampling and the classifier einsum
 are NOT part of this (PyTorch in the reference, not rebuilt), so this is the
 throughput of the rows SURVEY section 8 puts on the hot path plus row f1, not a
 full VEON end-to-end number.
@@ -24,10 +25,11 @@ import torch
 import torch.nn.functional as F
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from veon_amd import synthetic  # noqa: E402
+from veon_amd import conv3d_ops, synthetic  # noqa: E402
 from veon_amd.graphs import GraphedCallable  # noqa: E402
 from veon_amd.models import build_neck  # noqa: E402
-from veon_amd.models.semantic_net import AlignBody3D, ClipVisualTrunk  # noqa: E402
+from veon_amd.models.semantic_net import (AlignBody3D, ClipVisualTrunk,  # noqa: E402
+                                          PredHead3DOcc, PredHead3DSem)
 
 
 def timeit(fn, iters=20):
@@ -62,6 +64,9 @@ def main():
                          ds_feat=[2, 2, 2])).to(dev).eval()
     vt.sync_free = True
     body = AlignBody3D(256, 4).to(dev).eval()
+    occ_head = PredHead3DOcc(256, 2).to(dev).eval()
+    sem_head = PredHead3DSem(256, 768).to(dev).eval()
+    lifted = conv3d_ops.PaddedVolume(1, 256, 8, 100, 100, dev)
     rig = synthetic.make_rig(1, 6, size)
     geom = [t.to(dev) for t in synthetic.rig_inputs(rig)]
     img = torch.randn(6, 3, *size, device=dev)
@@ -104,7 +109,10 @@ def main():
         f = sem_branch(img)
 
         def lift_body(feat, depth):
-            return body(vt([feat] + geom, depth))
+            # the fused max-pool kernel writes the body's padded bf16 input; the
+            # heads read the body's padded output: no pack / unpack in between
+            x = body(vt([feat] + geom, depth, out_volume=lifted), return_volume=True)
+            return occ_head(x), sem_head(x)
 
         # NOTE: lift and body run eagerly here.  Each replays fine from its own
         # hipGraph (tests, bench.py, tools/time_forward.py), but in this script a
@@ -119,7 +127,8 @@ def main():
 
         out = whole(img)
         torch.cuda.synchronize()
-        print('depth', tuple(d.shape), 'feat', tuple(f.shape), 'out', tuple(out.shape), flush=True)
+        print('depth', tuple(d.shape), 'feat', tuple(f.shape), 'out',
+              [tuple(o.shape) for o in out], flush=True)
         t_e = timeit(lambda: g_enc(x252))
         t_d = timeit(lambda: depth_branch(img))
         print('depth branch %.2f ms (encoder graph %.2f ms, DPT head %s)' % (
@@ -129,10 +138,10 @@ def main():
         t_l = timeit(lambda: vt([f] + geom, d))
         print('lift %.3f ms' % t_l, flush=True)
         t_lb = timeit(lambda: lift_body(f, d))
-        print('lift + Conv3d body %.3f ms' % t_lb, flush=True)
+        print('lift + Conv3d body + occ/sem heads %.3f ms' % t_lb, flush=True)
         t_w = timeit(lambda: whole(img))
         print('chained %.2f ms' % t_w, flush=True)
-    print('%s: depth %.2f | semantic %.2f | lift %.3f | lift+body %.3f | chained %.2f ms '
+    print('%s: depth %.2f | semantic %.2f | lift %.3f | lift+body+heads %.3f | chained %.2f ms '
           '-> %.1f 6-cam samples/s' % (enc, t_d, t_s, t_l, t_lb, t_w, 1e3 / t_w))
 
 

@@ -523,7 +523,10 @@ __device__ __forceinline__ float key_float(int k) {
   return __int_as_float(k ^ ((k >> 31) & 0x7fffffff));
 }
 
-template <int VEC, typename FT>
+// PADDED: the result goes, rounded to bf16, into the interior of the zero-padded
+// channels-last grid [B][Zo+2][Yo+2][Xo+2][C] that the Conv3d body consumes
+// (csrc/conv3d.hip) instead of the (B,C,Zo,Yo,Xo) fp32 tensor.
+template <int VEC, typename FT, bool PADDED = false>
 __global__ __launch_bounds__(kBlock) void k_pool_maxpool_cf(
     PoolArgs a, const int* __restrict__ row_first, int c, int cs, int Z, int Y,
     int X, int dz, int dy, int dx, float* __restrict__ out) {
@@ -567,6 +570,24 @@ __global__ __launch_bounds__(kBlock) void k_pool_maxpool_cf(
     }
   __syncthreads();
   const int full = dz * dy * dx;
+  if constexpr (PADDED) {
+    unsigned short* ob =
+        reinterpret_cast<unsigned short*>(out) +
+        ((((int64_t)b * (Zo + 2) + zo + 1) * (Yo + 2) + yo + 1) * (Xo + 2) + 1) *
+            (int64_t)c + c0;
+    for (int i = tid; i < nch * Xo; i += kBlock) {
+      const int xo = i / nch;       // lanes run over channels: 2-byte stores,
+      const int cc = i - xo * nch;  // channel-contiguous per voxel
+      const int n = occ[xo];
+      float v = 0.f;
+      if (n > 0) {
+        v = key_float(tile[cc * Xo + xo]);
+        if (n < full && !(v > 0.f)) v = 0.f;
+      }
+      ob[(int64_t)xo * c + cc] = __builtin_bit_cast(unsigned short, (__bf16)v);
+    }
+    return;
+  }
   float* obase =
       out + ((((int64_t)b * c + c0) * Zo + zo) * Yo + yo) * (int64_t)Xo;
   const int64_t cstride = (int64_t)Zo * Yo * Xo;
@@ -771,7 +792,7 @@ int veon_bev_pool_row_table(int n_intervals, int n_points, int batch,
   return launch_status();
 }
 
-int veon_bev_pool_v2_fwd_maxpool_ex(int c, int n_intervals, int batch, int Z,
+static int maxpool_impl(bool padded, int c, int n_intervals, int batch, int Z,
                                     int Y, int X, int dz, int dy, int dx,
                                     const float* depth, const void* feat,
                                     int feat_dtype, const int* ranks_depth,
@@ -805,8 +826,16 @@ int veon_bev_pool_v2_fwd_maxpool_ex(int c, int n_intervals, int batch, int Z,
   const dim3 grid((unsigned)orows, (unsigned)slabs);
   hipStream_t s = static_cast<hipStream_t>(stream);
 #define VEON_LAUNCH_MP(VEC, FT)                                               \
-  hipLaunchKernelGGL((k_pool_maxpool_cf<VEC, FT>), grid, dim3(kBlock), lds, s, \
-                     a, row_first, c, cs, Z, Y, X, dz, dy, dx, out)
+  do {                                                                        \
+    if (padded)                                                               \
+      hipLaunchKernelGGL((k_pool_maxpool_cf<VEC, FT, true>), grid,            \
+                         dim3(kBlock), lds, s, a, row_first, c, cs, Z, Y, X,  \
+                         dz, dy, dx, out);                                    \
+    else                                                                      \
+      hipLaunchKernelGGL((k_pool_maxpool_cf<VEC, FT, false>), grid,           \
+                         dim3(kBlock), lds, s, a, row_first, c, cs, Z, Y, X,  \
+                         dz, dy, dx, out);                                    \
+  } while (0)
   if (feat_dtype == VEON_FEAT_F32) {
     if ((c % 4 == 0) && (cs % 4 == 0) && aligned16(feat))
       VEON_LAUNCH_MP(4, FeatF32);
@@ -829,6 +858,36 @@ int veon_bev_pool_v2_fwd_maxpool_ex(int c, int n_intervals, int batch, int Z,
   }
 #undef VEON_LAUNCH_MP
   return launch_status();
+}
+
+int veon_bev_pool_v2_fwd_maxpool_ex(int c, int n_intervals, int batch, int Z,
+                                    int Y, int X, int dz, int dy, int dx,
+                                    const float* depth, const void* feat,
+                                    int feat_dtype, const int* ranks_depth,
+                                    const int* ranks_feat, const int* ranks_bev,
+                                    const int* interval_starts,
+                                    const int* interval_lengths,
+                                    const int* row_first, float* out,
+                                    void* stream) {
+  return maxpool_impl(false, c, n_intervals, batch, Z, Y, X, dz, dy, dx, depth,
+                      feat, feat_dtype, ranks_depth, ranks_feat, ranks_bev,
+                      interval_starts, interval_lengths, row_first, out, stream);
+}
+
+int veon_bev_pool_v2_fwd_maxpool_padded(int c, int n_intervals, int batch, int Z,
+                                        int Y, int X, int dz, int dy, int dx,
+                                        const float* depth, const void* feat,
+                                        int feat_dtype, const int* ranks_depth,
+                                        const int* ranks_feat,
+                                        const int* ranks_bev,
+                                        const int* interval_starts,
+                                        const int* interval_lengths,
+                                        const int* row_first,
+                                        void* out_padded_bf16, void* stream) {
+  return maxpool_impl(true, c, n_intervals, batch, Z, Y, X, dz, dy, dx, depth,
+                      feat, feat_dtype, ranks_depth, ranks_feat, ranks_bev,
+                      interval_starts, interval_lengths, row_first,
+                      static_cast<float*>(out_padded_bf16), stream);
 }
 
 int veon_bev_pool_v2_fwd_maxpool(int c, int n_intervals, int batch, int Z, int Y,

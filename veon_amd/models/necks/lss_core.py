@@ -159,9 +159,10 @@ class LSSCore(_Base):
             bev_feat = torch.cat(bev_feat.unbind(dim=2), 1)
         return bev_feat
 
-    def _lift_maxpool(self, input, depth, feat, ds):
+    def _lift_maxpool(self, input, depth, feat, ds, out_volume=None):
         """forward's pool + (dz,dy,dx) block max in one kernel (inference).
-        depth (B,N,D,H,W), feat (B,N,C,H,W) -> (B,C,Z/dz,Y/dy,X/dx)."""
+        depth (B,N,D,H,W), feat (B,N,C,H,W) -> (B,C,Z/dz,Y/dy,X/dx), or into
+        ``out_volume`` (the Conv3d body's padded bf16 input)."""
         B = depth.shape[0]
         shape = self._bev_feat_shape(B, feat.shape[2])
         feat = feat.permute(0, 1, 3, 4, 2)
@@ -169,7 +170,8 @@ class LSSCore(_Base):
             self.pre_compute(input)
             return _bp.bev_pool_v2_maxpool(
                 depth, feat, self.ranks_depth, self.ranks_feat, self.ranks_bev,
-                shape, self.interval_starts, self.interval_lengths, ds)
+                shape, self.interval_starts, self.interval_lengths, ds,
+                out_volume=out_volume)
         sensor2ego, _, cam2imgs, post_rots, post_trans, bda = input[1:7]
         if self.sync_free:
             pri, comb, trans = _prep._HIP_PREPARE.camera_matrices(
@@ -181,7 +183,7 @@ class LSSCore(_Base):
             return _bp.bev_pool_v2_maxpool(
                 depth, feat, pre.ranks_depth, pre.ranks_feat, pre.ranks_bev,
                 shape, pre.interval_starts, pre.interval_lengths, ds,
-                counts=pre.counts)
+                counts=pre.counts, out_volume=out_volume)
         pri, comb, trans = _prep.camera_matrices(sensor2ego, cam2imgs, post_rots)
         ranks = _prep.prepare_from_matrices(
             self.frustum, pri, post_trans, comb, trans, bda,
@@ -189,7 +191,8 @@ class LSSCore(_Base):
         if ranks[0] is None:
             return None
         rb, rd, rf, st, ln = ranks
-        return _bp.bev_pool_v2_maxpool(depth, feat, rd, rf, rb, shape, st, ln, ds)
+        return _bp.bev_pool_v2_maxpool(depth, feat, rd, rf, rb, shape, st, ln, ds,
+                                       out_volume=out_volume)
 
     # ---------------------------------------------------------- entry points
     def pre_compute(self, input):

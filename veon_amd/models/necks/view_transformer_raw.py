@@ -105,18 +105,27 @@ class LSSViewTransformerRaw(LSSCore):
         return z % self.ds[0] == 0 and y % self.ds[1] == 0 and x % self.ds[2] == 0
 
     # ---------------------------------------------------------------- forward
-    def forward(self, input, depth, stereo_metas=None):
+    def forward(self, input, depth, stereo_metas=None, out_volume=None):
         """input = (tran_feat (B,N,C,Hf,Wf), sensor2ego, ego2global, intrins,
         post_rots, post_trans, bda); depth (B,N,D,Hf,Wf).  Returns the pooled
         volume (B,C,Z,Y,X), max-pooled by ``ds_feat`` when any factor != 1
-        (:537-555)."""
+        (:537-555).  veon_amd extension: ``out_volume`` (a
+        ``conv3d_ops.PaddedVolume``) receives the max-pooled volume in the
+        Conv3d body's padded bf16 layout and is returned instead (fused
+        inference path only)."""
         tran_feat = input[0]
         B, N, C, H, W = tran_feat.shape
+        if out_volume is not None and not self._can_fuse_ds(tran_feat):
+            raise ValueError('out_volume needs the fused inference max-pool path '
+                             '(ROCm tensors, no grad, ds_feat dividing the grid)')
         if self._can_fuse_ds(tran_feat):
             out = self._lift_maxpool(input, depth.view(B, N, self.D, H, W),
-                                     tran_feat, self.ds)
+                                     tran_feat, self.ds, out_volume=out_volume)
             if out is not None:
                 return out
+            if out_volume is not None:   # empty grid: the volume is all zeros
+                out_volume.rows.zero_()
+                return out_volume
         tran_feat = tran_feat.view(B * N, C, H, W)
         depth = depth.view(B * N, depth.shape[2], H, W)
         bev_feat = self.view_transform(input, depth, tran_feat)

@@ -231,7 +231,11 @@ class AlignBody3D(nn.Module):
         """``return_volume``: hand the result over as the PaddedVolume the
         prediction heads consume directly (no unpack / re-pack)."""
         blocks = list(self.layers_3d_body)[start:stop]
-        if not self._use_hip(x):
+        from_volume = isinstance(x, conv3d_ops.PaddedVolume)
+        if from_volume and not (self.use_hip and not self.training
+                                and all(b.hip_supported() for b in blocks)):
+            x, from_volume = conv3d_ops.unpack(x), False
+        if not from_volume and not self._use_hip(x):
             for blk in blocks:
                 x = blk(x)
             return x
@@ -239,10 +243,21 @@ class AlignBody3D(nn.Module):
             self._hip = [(b.conv1.folded(), b.conv2.folded())
                          for b in self.layers_3d_body]
         folded = self._hip[start:stop]
-        a, t, o = self._volumes(x.shape, x.device)
-        conv3d_ops.pack(x, out=a)
+        internal = list(self._volumes(x.shape, x.device))
+        external = None
+        if from_volume:   # e.g. written by the lift's fused max-pool kernel
+            src = x
+            if not any(x is b for b in internal):
+                external = x               # read only, never overwritten
+        else:
+            src = internal[0]
+            conv3d_ops.pack(x, out=src)
+        pool = [b for b in internal if b is not src]
         for (w1, s1, b1), (w2, s2, b2) in folded:
-            conv3d_ops.conv3d_k3(a, w1, s1, b1, relu=True, out=t)
-            conv3d_ops.conv3d_k3(t, w2, s2, b2, resid=a, relu=True, out=o)
-            a, o = o, a
+            tmp, dst = pool[0], pool[1]
+            conv3d_ops.conv3d_k3(src, w1, s1, b1, relu=True, out=tmp)
+            conv3d_ops.conv3d_k3(tmp, w2, s2, b2, resid=src, relu=True, out=dst)
+            pool = [tmp] + pool[2:] + ([src] if src is not external else [])
+            src = dst
+        a = src
         return a if return_volume else conv3d_ops.unpack(a)

@@ -294,12 +294,15 @@ def build_row_table(ranks_bev, interval_starts, batch, voxels_per_batch,
 
 def bev_pool_v2_maxpool(depth, feat, ranks_depth, ranks_feat, ranks_bev,
                         bev_feat_shape, interval_starts, interval_lengths, ds,
-                        counts=None):
+                        counts=None, out_volume=None):
     """Inference-only fusion of ``bev_pool_v2`` with the (dz,dy,dx) block max of
     LSSViewTransformerRaw.forward (view_transformer_raw.py:545-553): returns
     (B, C, Z/dz, Y/dy, X/dx) without writing the full-resolution volume.
     Bit-equal to max-pooling ``bev_pool_v2``'s output.  Intervals must be
-    ascending in voxel rank (what the prepare produces)."""
+    ascending in voxel rank (what the prepare produces).  ``out_volume`` (a
+    ``conv3d_ops.PaddedVolume`` of shape (B,C,Z/dz,Y/dy,X/dx)) receives the
+    result rounded to bf16 in the Conv3d body's input layout instead, and is
+    returned."""
     depth = depth.contiguous().float()
     feat = _inference_feat(feat, depth)
     B, Z, Y, X, C = [int(s) for s in bev_feat_shape]
@@ -312,6 +315,19 @@ def bev_pool_v2_maxpool(depth, feat, ranks_depth, ranks_feat, ranks_bev,
     else:
         table = build_row_table(ranks_bev, interval_starts, B, Z * Y * X, X,
                                 counts=counts, attach=False)
+    if out_volume is not None:
+        if out_volume.shape != (B, C, Z // dz, Y // dy, X // dx):
+            raise _lib.VeonHipError('out_volume shape %r does not match the pooled '
+                                    'volume' % (out_volume.shape,))
+        with torch.cuda.device(dev):
+            st = _lib.lib().veon_bev_pool_v2_fwd_maxpool_padded(
+                C, interval_starts.numel(), B, Z, Y, X, dz, dy, dx,
+                _lib.ptr(depth), _lib.ptr(feat), _feat_code(feat),
+                _lib.ptr(ranks_depth), _lib.ptr(ranks_feat), _lib.ptr(ranks_bev),
+                _lib.ptr(interval_starts), _lib.ptr(interval_lengths),
+                _lib.ptr(table), _lib.ptr(out_volume.rows), _lib.stream_ptr(dev))
+        _lib.check(st, 'veon_bev_pool_v2_fwd_maxpool_padded')
+        return out_volume
     out = torch.empty((B, C, Z // dz, Y // dy, X // dx), dtype=torch.float32,
                       device=dev)
     with torch.cuda.device(dev):
