@@ -29,6 +29,8 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 
+MFMA_PEAK_TFLOPS = 2500.0  # dense bf16, same guide
+
 WORKLOADS = {
     # tag: (grid key, input_size, n_cams, C, neck type)
     'S2': ('GRID_S2', (256, 704), 6, 80, 'LSSViewTransformer'),
@@ -42,7 +44,9 @@ def parse():
     p.add_argument('--gpus', type=int, default=1)
     p.add_argument('--steps', type=int, default=200)
     p.add_argument('--warmup', type=int, default=20)
-    p.add_argument('--workload', default='S2', choices=sorted(WORKLOADS))
+    p.add_argument('--workload', default='S2', choices=sorted(WORKLOADS) + ['VEONB'],
+                   help='S2 (default, BASELINE configs[1]) / SV / S1: the lift; VEONB: the '
+                        'chained hot path of BASELINE configs[2] (tools/hotpath_bench.py)')
     p.add_argument('--no-graph', action='store_true',
                    help='eager launches instead of a captured hipGraph')
     p.add_argument('--shard', default='replicas', choices=['replicas', 'cameras'],
@@ -62,6 +66,54 @@ def algorithmic_bytes(n_cams, hf, wf, C, D, p_kept, n_intervals, n_vox, batch=1)
     + the output volume written once (zeros included), fp32/int32."""
     return 4 * (batch * n_cams * hf * wf * C + batch * n_cams * D * hf * wf +
                 3 * p_kept + 2 * n_intervals + batch * n_vox * C)
+
+
+def bench_hotpath(args, rank, world, dev, dist):
+    """BASELINE configs[2] shape: DA-V2 ViT-B + CLIP ViT-B/16 + lift + Conv3d body
+    + heads, bf16, one 6-camera 256x704 sample per step (replicas for N > 1).
+    The roofline object is the dominant MFMA kernel (the 3x3x3 conv body)."""
+    from tools import hotpath_bench
+    r = hotpath_bench.run('vitb', head_bf16=True, dev=str(dev), iters=5, verbose=False)
+    step = r['step']
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            step()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        el = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([el], dtype=torch.float64,
+                         device='cpu' if dist.get_backend() == 'gloo' else dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    if rank != 0:
+        return
+    ms = el / args.steps * 1e3
+    body_flops = 8 * 2.0 * 8 * 100 * 100 * 256 * 256 * 27
+    tf = body_flops / (r['body_ms'] * 1e-3) / 1e12
+    print(json.dumps({
+        'metric': '6cam_hotpath_samples_per_sec', 'value': round(world * 1e3 / ms, 2),
+        'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': round(ms, 4), 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+        'config': {'workload': 'VEONB: 6-cam 256x704 -> DA-V2 ViT-B (MFMA encoder, DPT head '
+                               'PyTorch/MIOpen bf16) + CLIP ViT-B/16 trunk (MFMA) + sync-free '
+                               'lift (D=88, C=256, 200x200x16, fused 2x2x2 max-pool) + 4x '
+                               'ResBlock3D body + occ/sem heads (MFMA); random weights; SAN side '
+                               'adapter / HSA / upsample / classifier not included',
+                   'parallelism': 'replicas x%d' % world,
+                   'stages_ms': {k: round(v, 3) for k, v in r.items() if k.endswith('_ms')}},
+        'roofline': {'kernel': 'k_conv3d_k3 (8 launches, AlignNetOcc3D body)', 'bound': 'mfma',
+                     'achieved': round(tf, 1), 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                     'frac': round(tf / MFMA_PEAK_TFLOPS, 4), 'traffic': None},
+        'cpu_baseline': None}))
 
 
 def main():
@@ -92,6 +144,9 @@ def main():
     from veon_amd.models import build_neck
     from veon_amd.ops.bev_pool_v2 import bev_pool as bp
     _lib.lib()  # fail loudly if the HIP library is missing
+
+    if args.workload == 'VEONB':
+        return bench_hotpath(args, rank, world, dev, dist)
 
     grid_key, input_size, n_cams, C, neck_type = WORKLOADS[args.workload]
     grid = getattr(synthetic, grid_key)

@@ -46,9 +46,15 @@ def timeit(fn, iters=20):
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith('--')]
     enc = args[0] if args else 'vitb'
-    head_bf16 = '--head-bf16' in sys.argv
-    graph_clip = '--graph-clip' in sys.argv
-    dev = 'cuda:0'
+    run(enc, '--head-bf16' in sys.argv, '--graph-clip' in sys.argv)
+
+
+def run(enc='vitb', head_bf16=True, graph_clip=False, dev='cuda:0', iters=20,
+        verbose=True):
+    """Build the chain, time its stages and the whole; returns a dict (ms)."""
+    def say(*a):
+        if verbose:
+            print(*a, flush=True)
     size = (256, 704)
     torch.manual_seed(0)
     cfgs = {'vitb': dict(encoder='vitb', features=128, out_channels=[96, 192, 384, 768]),
@@ -127,22 +133,27 @@ def main():
 
         out = whole(img)
         torch.cuda.synchronize()
-        print('depth', tuple(d.shape), 'feat', tuple(f.shape), 'out',
-              [tuple(o.shape) for o in out], flush=True)
-        t_e = timeit(lambda: g_enc(x252))
-        t_d = timeit(lambda: depth_branch(img))
-        print('depth branch %.2f ms (encoder graph %.2f ms, DPT head %s)' % (
-            t_d, t_e, 'bf16 autocast' if head_bf16 else 'fp32'), flush=True)
-        t_s = timeit(lambda: sem_branch(img))
-        print('semantic trunk %.2f ms (%s)' % (t_s, 'hipGraph' if graph_clip else 'eager'), flush=True)
-        t_l = timeit(lambda: vt([f] + geom, d))
-        print('lift %.3f ms' % t_l, flush=True)
-        t_lb = timeit(lambda: lift_body(f, d))
-        print('lift + Conv3d body + occ/sem heads %.3f ms' % t_lb, flush=True)
-        t_w = timeit(lambda: whole(img))
-        print('chained %.2f ms' % t_w, flush=True)
-    print('%s: depth %.2f | semantic %.2f | lift %.3f | lift+body+heads %.3f | chained %.2f ms '
-          '-> %.1f 6-cam samples/s' % (enc, t_d, t_s, t_l, t_lb, t_w, 1e3 / t_w))
+        say('depth', tuple(d.shape), 'feat', tuple(f.shape), 'out',
+            [tuple(o.shape) for o in out])
+        t_e = timeit(lambda: g_enc(x252), iters)
+        t_d = timeit(lambda: depth_branch(img), iters)
+        say('depth branch %.2f ms (encoder graph %.2f ms, DPT head %s)' % (
+            t_d, t_e, 'bf16 autocast' if head_bf16 else 'fp32'))
+        t_s = timeit(lambda: sem_branch(img), iters)
+        say('semantic trunk %.2f ms (%s)' % (t_s, 'hipGraph' if graph_clip else 'eager'))
+        t_l = timeit(lambda: vt([f] + geom, d), iters)
+        say('lift %.3f ms' % t_l)
+        t_b = timeit(lambda: body(lifted, return_volume=True), iters)
+        say('Conv3d body %.3f ms' % t_b)
+        t_lb = timeit(lambda: lift_body(f, d), iters)
+        say('lift + Conv3d body + occ/sem heads %.3f ms' % t_lb)
+        t_w = timeit(lambda: whole(img), iters)
+        say('chained %.2f ms' % t_w)
+    say('%s: depth %.2f | semantic %.2f | lift %.3f | lift+body+heads %.3f | chained %.2f ms '
+        '-> %.1f 6-cam samples/s' % (enc, t_d, t_s, t_l, t_lb, t_w, 1e3 / t_w))
+    return dict(encoder_ms=t_e, depth_branch_ms=t_d, semantic_ms=t_s, lift_ms=t_l,
+                body_ms=t_b, lift_body_heads_ms=t_lb, chained_ms=t_w,
+                step=lambda: whole(img))
 
 
 if __name__ == '__main__':
