@@ -61,6 +61,28 @@ def parse():
     return p.parse_args()
 
 
+def committed_pmc_traffic(workload):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes
+    (profiles/r01_pmc_hbm_bytes.json: two separate `rocprofv3 --pmc` runs of this
+    script, FETCH_SIZE and WRITE_SIZE in KiB).  WRITE_SIZE is exact for these
+    stores; FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950
+    (an upper bound here: the guide calibrates the x2 for wide streaming reads,
+    these are gathers).  None when the file or the kernel is missing."""
+    if workload != 'S2':
+        return None, None
+    path = os.path.join(ROOT, 'profiles', 'r01_pmc_hbm_bytes.json')
+    try:
+        with open(path) as f:
+            data = json.load(f)
+        for name, c in data.items():
+            if 'k_pool_fused_cf<4, 32' in name:
+                b = (c['WRITE_SIZE']['mean_KiB'] + 2.0 * c['FETCH_SIZE']['mean_KiB']) * 1024.0
+                return round(b), 'profiles/r01_pmc_hbm_bytes.json (WRITE_SIZE + 2 x FETCH_SIZE)'
+    except (OSError, KeyError, ValueError):
+        pass
+    return None, None
+
+
 def algorithmic_bytes(n_cams, hf, wf, C, D, p_kept, n_intervals, n_vox, batch=1):
     """feat once + depth once + 3 rank arrays + 2 interval arrays
     + the output volume written once (zeros included), fp32/int32."""
@@ -290,6 +312,9 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = (world if args.shard == 'replicas' else 1) * args.steps / elapsed
 
+    traffic, traffic_source = args.pmc_traffic, 'command line'
+    if traffic is None:
+        traffic, traffic_source = committed_pmc_traffic(args.workload)
     result = {
         'metric': '6cam_lift_samples_per_sec',
         'value': round(value, 2),
@@ -321,7 +346,8 @@ def main():
             'peak': HBM_PEAK_GBS,
             'unit': 'GB/s',
             'frac': round(achieved / HBM_PEAK_GBS, 4),
-            'traffic': args.pmc_traffic,
+            'traffic': traffic,
+            'traffic_source': traffic_source,
             'algorithmic_bytes': alg,
             'kernel_ms': round(kernel_ms, 5),
         },
