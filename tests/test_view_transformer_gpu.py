@@ -379,3 +379,24 @@ def test_native_entry_points_actually_ran():
     for name in ('veon_downsample_depth', 'veon_two_hot_depth', 'veon_lss_prepare',
                  'veon_bev_pool_row_table', 'veon_bev_pool_v2_fwd_maxpool_ex'):
         assert name in ran, (name, ran)
+
+
+def test_persistent_output_is_tuned_once_and_identical():
+    """persistent_output: the accelerate path keeps one (placement-tuned) output
+    volume, returns it on every call, and computes the same values."""
+    g = load_golden('lss_mid')
+    vt = _raw_from_golden(g, accelerate=True)
+    vt.fuse_ds = False
+    feat, depth = dev(g['feat']), dev(g['two_hot'])
+    with torch.no_grad():
+        want = vt([feat] + _inputs(g), depth).clone()
+        vt.persistent_output = True
+        a = vt([feat] + _inputs(g), depth)
+        info = vt.placement_info
+        assert info is not None and 1 <= info['candidates'] <= 40
+        a_copy = a.clone()
+        b = vt([feat] + _inputs(g), depth)
+    assert vt.placement_info is info          # tuned once
+    assert torch.equal(a_copy, want) and torch.equal(b, want)
+    # the un-pooled volume is the persistent buffer both times
+    assert vt._out_buf is not None and vt._out_buf.shape[1] == feat.shape[2]

@@ -45,25 +45,28 @@ def main():
             assert r == 0
         return f
 
-    arena = torch.empty(nbytes + (64 << 20), dtype=torch.uint8, device=dev)
-    base = arena.data_ptr()
-    print('arena base %#x (mod 2MiB = %#x)' % (base, base % (2 << 20)))
-    offs = [k << 20 for k in range(0, 36)] + [(k << 19) + (8 << 20) for k in range(-3, 4)]
-    res = {}
-    for rnd in range(2):
-        for o in offs:
-            res.setdefault(o, []).append(timeit(run(base + o)))
-    for o in offs:
-        a_ = base + o
-        print('arena +%5.1f MiB  (addr>>20)&31=%2d  %s us' % (
-            o / 2**20, (a_ >> 20) & 31, ' '.join('%6.2f' % t for t in res[o])))
+    # distribution over many separate allocations, and stability on re-timing
     keep = []
-    for i in range(8):
-        pad = torch.empty((3 + 5 * i) << 20, dtype=torch.uint8, device=dev)
+    res = []
+    for i in range(32):
         b = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        keep += [pad, b]
-        t = [timeit(run(b.data_ptr())) for _ in range(2)]
-        print('separate buf %d @%#x  %6.2f %6.2f us' % (i, b.data_ptr(), t[0], t[1]))
+        keep.append(b)
+        res.append([timeit(run(b.data_ptr()), 20)])
+    for rnd in range(2):
+        for i, b in enumerate(keep):
+            res[i].append(timeit(run(b.data_ptr()), 20))
+    for i, b in enumerate(keep):
+        print('buf %2d @%#x  %s us' % (i, b.data_ptr(), ' '.join('%6.2f' % t for t in res[i])))
+    fast = [i for i in range(len(keep)) if min(res[i]) < 37.0]
+    print('fast buffers:', fast, ' (%d of %d)' % (len(fast), len(keep)))
+    # does a fast buffer stay fast after being freed and re-allocated?
+    if fast:
+        ptr = keep[fast[0]].data_ptr()
+        keep[fast[0]] = None
+        b = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        print('re-allocated: same address %s, %6.2f us' % (b.data_ptr() == ptr, timeit(run(b.data_ptr()), 20)))
+        keep.append(b)
+    arena = keep[0]
     # output of the product wrapper (allocator-reused block), as kbench measures it
     shape = (1, Z, Y, X, C)
     f = lambda: bp._fused_forward(depth, feat, rd, rf, rb, st, ln, shape, _lib.LAYOUT_BCZYX)

@@ -49,6 +49,16 @@ class LSSCore(_Base):
         # reference's odd-shaped dummy).  Makes accelerate=False capturable in
         # a hipGraph.
         self.sync_free = False
+        # veon_amd extension (default off): with cached ranks (accelerate=True)
+        # at inference, keep ONE output volume alive across calls and return it
+        # every time (the caller must consume it before the next call -- what a
+        # hipGraph replay implies anyway).  The buffer is picked once among a
+        # few candidate allocations by timing the pool kernel on each
+        # (veon_amd/placement.py: the same launch is ~15 % faster into a
+        # well-placed allocation).
+        self.persistent_output = False
+        self._out_buf = None
+        self.placement_info = None
 
     # ------------------------------------------------------------------ grid
     def create_grid_infos(self, x, y, z, **kwargs):
@@ -207,10 +217,14 @@ class LSSCore(_Base):
             feat = tran_feat.view(B, N, self.out_channels, H, W)
             feat = feat.permute(0, 1, 3, 4, 2)
             depth = depth.view(B, N, self.D, H, W)
+            shape = self._bev_feat_shape(B, feat.shape[-1])
+            out = None
+            if (self.persistent_output and feat.is_cuda
+                    and not torch.is_grad_enabled()):
+                out = self._persistent_volume(depth, feat, shape)
             bev_feat = bev_pool_v2(
                 depth, feat, self.ranks_depth, self.ranks_feat, self.ranks_bev,
-                self._bev_feat_shape(B, feat.shape[-1]), self.interval_starts,
-                self.interval_lengths)
+                shape, self.interval_starts, self.interval_lengths, out=out)
             bev_feat = bev_feat.squeeze(2)
         elif (self.sync_free and tran_feat.is_cuda
               and not torch.is_grad_enabled()):
@@ -225,6 +239,21 @@ class LSSCore(_Base):
         if self._core_returns_depth:
             return bev_feat, depth
         return bev_feat
+
+    def _persistent_volume(self, depth, feat, shape):
+        Bv, Z, Y, X, C = (int(v) for v in shape)
+        want = (Bv, C, Z, Y, X)
+        if self._out_buf is None or tuple(self._out_buf.shape) != want \
+                or self._out_buf.device != feat.device:
+            from ... import placement
+
+            def probe(o):
+                bev_pool_v2(depth, feat, self.ranks_depth, self.ranks_feat,
+                            self.ranks_bev, shape, self.interval_starts,
+                            self.interval_lengths, out=o)
+            self._out_buf, self.placement_info = placement.best_placed(
+                probe, want, torch.float32, feat.device)
+        return self._out_buf
 
     def view_transform(self, input, depth, tran_feat):
         if self.accelerate:

@@ -116,11 +116,18 @@ def build_plan(ranks_bev, interval_starts, batch, voxels_per_batch,
 
 
 def _fused_forward(depth, feat, ranks_depth, ranks_feat, ranks_bev,
-                   interval_starts, interval_lengths, bev_feat_shape, layout):
+                   interval_starts, interval_lengths, bev_feat_shape, layout,
+                   out=None):
     B, Z, Y, X, C = [int(s) for s in bev_feat_shape]
     dev = _lib.require_device(depth, feat, ranks_depth, ranks_feat, ranks_bev,
                               interval_starts, interval_lengths)
-    if layout == _lib.LAYOUT_BCZYX:
+    if out is not None:
+        want = (B, C, Z, Y, X) if layout == _lib.LAYOUT_BCZYX else (B, Z, Y, X, C)
+        if (tuple(out.shape) != want or out.dtype != torch.float32
+                or not out.is_contiguous() or out.device != dev):
+            raise _lib.VeonHipError('out must be a contiguous fp32 %r tensor on %s'
+                                    % (want, dev))
+    elif layout == _lib.LAYOUT_BCZYX:
         out = torch.empty((B, C, Z, Y, X), dtype=torch.float32, device=dev)
     else:
         out = torch.empty((B, Z, Y, X, C), dtype=torch.float32, device=dev)
@@ -220,20 +227,26 @@ class _BevPoolV2Fused(torch.autograd.Function):
 
 
 def bev_pool_v2(depth, feat, ranks_depth, ranks_feat, ranks_bev,
-                bev_feat_shape, interval_starts, interval_lengths):
+                bev_feat_shape, interval_starts, interval_lengths, out=None):
     """Drop-in for mmdet3d.ops.bev_pool_v2.bev_pool.bev_pool_v2
     (bev_pool.py:86-92): returns the (B,C,Z,Y,X) contiguous fp32 volume,
-    differentiable w.r.t. depth and feat."""
+    differentiable w.r.t. depth and feat.  veon_amd extension: ``out`` -- a
+    caller-owned (B,C,Z,Y,X) fp32 tensor the fused inference kernel writes
+    (every element) and returns, e.g. one chosen by ``placement.best_placed``;
+    ignored when a gradient is needed or the intervals are not sorted."""
     (depth, feat, ranks_depth, ranks_feat, ranks_bev, interval_starts,
      interval_lengths) = _prep_inputs(depth, feat, ranks_depth, ranks_feat,
                                       ranks_bev, interval_starts,
                                       interval_lengths)
     B, Z, Y, X, C = [int(s) for s in bev_feat_shape]
     if _can_fuse(ranks_bev, interval_starts, B * Z * Y * X):
-        if feat.dtype in _HALF:  # inference only, see _inference_feat
+        no_grad = not (torch.is_grad_enabled()
+                       and (depth.requires_grad or feat.requires_grad))
+        if feat.dtype in _HALF or (out is not None and no_grad):
+            # inference only (see _inference_feat): straight to the kernel
             return _fused_forward(depth, feat, ranks_depth, ranks_feat,
                                   ranks_bev, interval_starts, interval_lengths,
-                                  bev_feat_shape, _lib.LAYOUT_BCZYX)
+                                  bev_feat_shape, _lib.LAYOUT_BCZYX, out=out)
         return _BevPoolV2Fused.apply(depth, feat, ranks_depth, ranks_feat,
                                      ranks_bev, bev_feat_shape,
                                      interval_starts, interval_lengths)

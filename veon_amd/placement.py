@@ -1,0 +1,61 @@
+"""Output placement for the channels-first lift volume.
+
+The fused pool kernel writes 64-voxel rows of all C channel planes of the
+(B,C,Z,Y,X) volume at once, i.e. it touches C distinct regions 4*Z*Y*X bytes
+apart (2.56 MB at 200x200x16) per workgroup.  On MI355X the very same launch
+runs ~34 us into some 205 MB allocations and ~41 us into others (bimodal,
+stable per allocation, independent of the virtual address, neighbouring
+allocations tend to agree; a linear fill is insensitive) -- consistent with the
+size of the page-table fragments the driver could give the allocation
+(physical contiguity), which decides how many TLB entries the C planes need.
+See DESIGN.md section 4 and tools/addr_probe.py.
+
+A consumer that keeps ONE output buffer alive across calls (a hipGraph replay
+does so anyway) can therefore pick a well-placed one once: ``best_placed``
+times a probe on a handful of candidate allocations and keeps the fastest.
+"""
+import torch
+
+
+def _time(fn, out, iters):
+    fn(out)
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn(out)
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def best_placed(probe, shape, dtype=torch.float32, device=None, k_min=6, k_max=40,
+                iters=8, good=0.96, max_bytes=16 << 30):
+    """Allocate candidate tensors of ``shape`` (all alive at once, so they are
+    distinct allocations), time ``probe(out)`` on each and return
+    ``(best_tensor, info)``.  Stops early once a candidate is at least
+    ``1 - good`` faster than the median of those seen (the distribution is
+    bimodal; host launch gaps compress the measured ratio, hence the small
+    margin); at most ``max_bytes`` are held at a time; the losers are released
+    back to the driver."""
+    nbytes = torch.empty((), dtype=dtype).element_size()
+    for d in shape:
+        nbytes *= int(d)
+    k_max = max(1, min(k_max, max_bytes // max(nbytes, 1)))
+    k_min = min(k_min, k_max)
+    cands, times = [], []
+    for i in range(k_max):
+        t = torch.empty(shape, dtype=dtype, device=device)
+        cands.append(t)
+        times.append(_time(probe, t, iters))
+        if i + 1 >= k_min:
+            med = sorted(times)[len(times) // 2]
+            if min(times) < good * med:
+                break
+    best = min(range(len(times)), key=times.__getitem__)
+    out = cands[best]
+    info = {'candidates': len(cands), 'best_ms': times[best],
+            'median_ms': sorted(times)[len(times) // 2]}
+    del cands
+    torch.cuda.empty_cache()
+    return out, info
