@@ -48,7 +48,7 @@ def main():
     # distribution over many separate allocations, and stability on re-timing
     keep = []
     res = []
-    for i in range(32):
+    for i in range(int(os.environ.get('NBUF', 32))):
         b = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         keep.append(b)
         res.append([timeit(run(b.data_ptr()), 20)])
