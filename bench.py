@@ -282,6 +282,7 @@ def main():
             cfg2 = dict(cfg, accelerate=False)
             vt2 = build_neck(cfg2).to(dev).eval()
             vt2.sync_free = True
+            vt2.persistent_output = vt.persistent_output
 
             def step2():
                 o = vt2.view_transform(inp, depth, tran_feat)

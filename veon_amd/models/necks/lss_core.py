@@ -162,9 +162,15 @@ class LSSCore(_Base):
             self.frustum, pri, post_trans, comb, trans, bda,
             self.grid_lower_bound, self.grid_interval, self.grid_size,
             sync=False)
-        bev_feat = _bp.bev_pool_v2_prepared(
-            depth, feat.permute(0, 1, 3, 4, 2), pre,
-            self._bev_feat_shape(depth.shape[0], feat.shape[2]))
+        shape = self._bev_feat_shape(depth.shape[0], feat.shape[2])
+        feat_l = feat.permute(0, 1, 3, 4, 2)
+        out = None
+        if self.persistent_output:
+            out = self._persistent_volume(
+                depth, feat, shape,
+                probe=lambda o: _bp.bev_pool_v2_prepared(depth, feat_l, pre, shape,
+                                                         out=o))
+        bev_feat = _bp.bev_pool_v2_prepared(depth, feat_l, pre, shape, out=out)
         if self.collapse_z:
             bev_feat = torch.cat(bev_feat.unbind(dim=2), 1)
         return bev_feat
@@ -240,17 +246,18 @@ class LSSCore(_Base):
             return bev_feat, depth
         return bev_feat
 
-    def _persistent_volume(self, depth, feat, shape):
+    def _persistent_volume(self, depth, feat, shape, probe=None):
         Bv, Z, Y, X, C = (int(v) for v in shape)
         want = (Bv, C, Z, Y, X)
         if self._out_buf is None or tuple(self._out_buf.shape) != want \
                 or self._out_buf.device != feat.device:
             from ... import placement
 
-            def probe(o):
-                bev_pool_v2(depth, feat, self.ranks_depth, self.ranks_feat,
-                            self.ranks_bev, shape, self.interval_starts,
-                            self.interval_lengths, out=o)
+            if probe is None:
+                def probe(o):
+                    bev_pool_v2(depth, feat, self.ranks_depth, self.ranks_feat,
+                                self.ranks_bev, shape, self.interval_starts,
+                                self.interval_lengths, out=o)
             self._out_buf, self.placement_info = placement.best_placed(
                 probe, want, torch.float32, feat.device)
         return self._out_buf

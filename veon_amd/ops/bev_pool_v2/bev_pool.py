@@ -257,7 +257,7 @@ def bev_pool_v2(depth, feat, ranks_depth, ranks_feat, ranks_bev,
     return x.permute(0, 4, 1, 2, 3).contiguous()
 
 
-def bev_pool_v2_prepared(depth, feat, pre, bev_feat_shape):
+def bev_pool_v2_prepared(depth, feat, pre, bev_feat_shape, out=None):
     """Inference-only pooling straight from the device-resident output of the
     HIP prepare (``lss_prepare_hip.Prepared``): capacity-sized rank buffers and
     the plan the prepare emitted, no host synchronisation anywhere -- the whole
@@ -273,7 +273,11 @@ def bev_pool_v2_prepared(depth, feat, pre, bev_feat_shape):
         pre.plan = build_plan(pre.ranks_bev, pre.interval_starts, B, Z * Y * X,
                               attach=False, counts=pre.counts)
     dev = _lib.require_device(depth, feat, pre.ranks_bev)
-    out = torch.empty((B, C, Z, Y, X), dtype=torch.float32, device=dev)
+    if out is None:
+        out = torch.empty((B, C, Z, Y, X), dtype=torch.float32, device=dev)
+    elif (tuple(out.shape) != (B, C, Z, Y, X) or out.dtype != torch.float32
+          or not out.is_contiguous() or out.device != dev):
+        raise _lib.VeonHipError('out must be a contiguous fp32 (B,C,Z,Y,X) tensor')
     with torch.cuda.device(dev):
         st = _lib.lib().veon_bev_pool_v2_fwd_fused_ex(
             C, pre.interval_starts.numel(), B, Z * Y * X, _lib.ptr(depth),

@@ -45,7 +45,12 @@ def best_placed(probe, shape, dtype=torch.float32, device=None, k_min=6, k_max=4
     k_min = min(k_min, k_max)
     cands, times = [], []
     for i in range(k_max):
-        t = torch.empty(shape, dtype=dtype, device=device)
+        try:
+            t = torch.empty(shape, dtype=dtype, device=device)
+        except torch.cuda.OutOfMemoryError:
+            if not cands:
+                raise
+            break  # tune among what fits
         cands.append(t)
         times.append(_time(probe, t, iters))
         if i + 1 >= k_min:
