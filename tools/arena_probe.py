@@ -9,7 +9,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from tests import helpers  # noqa: E402
+from tools._inputs import lift_case  # noqa: E402
 from veon_amd import _lib, synthetic  # noqa: E402
 from veon_amd.ops.bev_pool_v2 import bev_pool as bp  # noqa: E402
 from tools.kbench import timeit  # noqa: E402
@@ -18,15 +18,11 @@ from tools.kbench import timeit  # noqa: E402
 def main():
     dev = 'cuda:0'
     grid, size, cams, C = synthetic.GRID_S2, (256, 704), 6, 80
-    ranks, coor, rig, fr, gsize = helpers.oracle_ranks(grid, size, cams)
-    rb, rd, rf, st, ln = ranks
-    D = fr.shape[0]
-    hf, wf = size[0] // 16, size[1] // 16
-    depth, feat = synthetic.make_depth_feat(1, cams, D, C, hf, wf, 0)
-    depth = depth.to(dev)
-    feat = feat.permute(0, 1, 3, 4, 2).contiguous().to(dev)
-    rb, rd, rf, st, ln = (torch.from_numpy(x).to(dev) for x in (rb, rd, rf, st, ln))
-    vpb = int(gsize[2]) * int(gsize[1]) * int(gsize[0])
+    case = lift_case(grid, size, cams, C, dev)
+    depth, feat = case['depth'], case['feat_nhwc']
+    rb, rd, rf, st, ln = (case[k] for k in ('rb', 'rd', 'rf', 'st', 'ln'))
+    gsize = case['gsize']
+    vpb = gsize[0] * gsize[1] * gsize[2]
     bp.mark_sorted(st, int(rb[0]), int(rb[-1]))
     plan = bp.build_plan(rb, st, 1, vpb)
     L = _lib.lib()

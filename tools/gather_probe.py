@@ -3,7 +3,7 @@
 structure, but every point reads feat row 0 / depth 0 (all gathers L1-hot)."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from tests import helpers
+from tools._inputs import lift_case
 from veon_amd import _lib, synthetic
 from veon_amd.ops.bev_pool_v2 import bev_pool as bp
 
@@ -16,12 +16,10 @@ def timeit(fn, iters=100):
     return e0.elapsed_time(e1) / iters * 1e3
 
 grid, size, cams, C = synthetic.GRID_S2, (256, 704), 6, 80
-(rb, rd, rf, st, ln), coor, rig, fr, gsize = helpers.oracle_ranks(grid, size, cams)
-D = fr.shape[0]
-depth, feat = synthetic.make_depth_feat(1, cams, D, C, 16, 44, 0)
 dev = 'cuda:0'
-depth = depth.to(dev); feat = feat.permute(0, 1, 3, 4, 2).contiguous().to(dev)
-rb, rd, rf, st, ln = (torch.from_numpy(x).to(dev) for x in (rb, rd, rf, st, ln))
+case = lift_case(grid, size, cams, C, dev)
+depth, feat = case['depth'], case['feat_nhwc']
+rb, rd, rf, st, ln = (case[k] for k in ('rb', 'rd', 'rf', 'st', 'ln'))
 bp.mark_sorted(st, 0, 640000 - 1)
 bp.build_plan(rb, st, 1, 640000)
 shape = (1, 16, 200, 200, C)

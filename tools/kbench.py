@@ -15,7 +15,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from tests import helpers  # noqa: E402
+from tools._inputs import lift_case  # noqa: E402
 from veon_amd import _lib, synthetic  # noqa: E402
 from veon_amd.ops.bev_pool_v2 import bev_pool as bp  # noqa: E402
 
@@ -51,16 +51,13 @@ def main():
     cfg = {'S2': (synthetic.GRID_S2, (256, 704), 6, 80),
            'SV': (synthetic.GRID_VEON, (512, 1408), 6, 256)}[tag]
     grid, size, cams, C = cfg
-    ranks, coor, rig, fr, gsize = helpers.oracle_ranks(grid, size, cams)
-    rb, rd, rf, st, ln = ranks
-    D = fr.shape[0]
-    hf, wf = size[0] // 16, size[1] // 16
-    depth, feat = synthetic.make_depth_feat(1, cams, D, C, hf, wf, 0)
     dev = 'cuda:0'
-    depth = depth.to(dev)
-    feat = feat.permute(0, 1, 3, 4, 2).contiguous().to(dev)
-    rb, rd, rf, st, ln = (torch.from_numpy(x).to(dev) for x in (rb, rd, rf, st, ln))
-    Z, Y, X = int(gsize[2]), int(gsize[1]), int(gsize[0])
+    case = lift_case(grid, size, cams, C, dev)
+    depth, feat = case['depth'], case['feat_nhwc']
+    rb, rd, rf, st, ln = (case[k] for k in ('rb', 'rd', 'rf', 'st', 'ln'))
+    D = case['D']
+    hf, wf = size[0] // 16, size[1] // 16
+    X, Y, Z = case['gsize']
     vpb = Z * Y * X
     shape = (1, Z, Y, X, C)
     alg = 4 * (cams * hf * wf * C + cams * D * hf * wf + 3 * rb.numel() +
