@@ -190,3 +190,33 @@ def test_lift_writes_the_body_input_directly():
         # chaining partial ranges through volumes
         c = body(body(vol, 0, 1, return_volume=True), 1, 2)
         assert torch.equal(a, c)
+
+
+def test_hip_body_and_heads_against_reference_vectors():
+    """The MFMA path on the reference-generated fixture (bf16 tolerance)."""
+    from tests.conftest import load_golden
+    from veon_amd.models.semantic_net import PredHead3DOcc, PredHead3DSem
+    g = load_golden('align_body_tiny')
+
+    def sd(tag):
+        return {k[len(tag) + 1:]: torch.from_numpy(g[k]) for k in g
+                if k.startswith(tag + '/')}
+    body = AlignBody3D(embed_dim=64, layer_depth=1)
+    body.layers_3d_body[0].load_state_dict(sd('block'), strict=True)
+    sem = PredHead3DSem(64, 24)
+    sem.load_state_dict(sd('sem'), strict=True)
+    occ = PredHead3DOcc(64, 2)
+    occ.load_state_dict(sd('occ'), strict=True)
+    body, sem, occ = body.to(DEV).eval(), sem.to(DEV).eval(), occ.to(DEV).eval()
+    x = torch.from_numpy(g['x']).to(DEV)
+    before = dict(_lib.CALLS)
+    with torch.no_grad():
+        vol = body(x, return_volume=True)
+        y = conv3d_ops.unpack(vol)
+        s = sem(vol)
+        o = occ(vol)      # 64 -> 16 -> 2: K = 16 is not MFMA-shaped, torch path
+    assert _lib.CALLS['veon_conv3d_k3_bf16'] - before.get('veon_conv3d_k3_bf16', 0) == 2
+    for got, key, tol in ((y, 'block_out', 1e-2), (s, 'sem_out', 2e-2), (o, 'occ_out', 2e-2)):
+        want = torch.from_numpy(g[key])
+        rel = ((got.cpu() - want).norm() / want.norm()).item()
+        assert rel < tol, (key, rel)
