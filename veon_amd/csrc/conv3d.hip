@@ -292,7 +292,7 @@ int veon_conv3d_k3_bf16(const void* in_padded, const void* w_bf16,
   // bigger ones, and a 3-stage counted-vmcnt DMA ring was not faster than this.
   struct Tile { int wm, wn, mt; };
   static const Tile wide[] = {{4, 4, 3}, {4, 4, 4}, {3, 4, 7}};   // 192/256/336 x 256
-  static const Tile narrow[] = {{2, 2, 2}, {2, 2, 4}};             // 64/128 x 128
+  static const Tile narrow[] = {{4, 2, 1}, {4, 2, 2}};             // 64/128 x 128, 8 waves
   const bool is_wide = Cout >= 256;
   const Tile* cands = is_wide ? wide : narrow;
   const int ncand = is_wide ? 3 : 2;
@@ -337,8 +337,8 @@ int veon_conv3d_k3_bf16(const void* in_padded, const void* w_bf16,
     if (VEON_TILE_IS(3, 4, 7)) VEON_LAUNCH_CONV(3, 4, 7, RELU, RESID);         \
     else if (VEON_TILE_IS(4, 4, 3)) VEON_LAUNCH_CONV(4, 4, 3, RELU, RESID);    \
     else if (VEON_TILE_IS(4, 4, 4)) VEON_LAUNCH_CONV(4, 4, 4, RELU, RESID);    \
-    else if (VEON_TILE_IS(2, 2, 4)) VEON_LAUNCH_CONV(2, 2, 4, RELU, RESID);    \
-    else VEON_LAUNCH_CONV(2, 2, 2, RELU, RESID);                               \
+    else if (VEON_TILE_IS(4, 2, 2)) VEON_LAUNCH_CONV(4, 2, 2, RELU, RESID);    \
+    else VEON_LAUNCH_CONV(4, 2, 1, RELU, RESID);                               \
   } while (0)
   if (relu) {
     if (R) VEON_LAUNCH_CONV_T(true, true); else VEON_LAUNCH_CONV_T(true, false);

@@ -71,16 +71,15 @@ __global__ __launch_bounds__(256) void k_layernorm(
 }
 
 // ----------------------------------------------------------------------- GEMM
-// (32*MT) x 128 output tile, BK = 64, 256 threads = 4 waves in 2(M) x 2(N), each
-// wave (16*MT) tokens x 64 features = MT x 4 MFMA tiles.  MT in {2,4} (tile
-// heights 64/128) is picked per shape by the launcher.  Operands go global -> LDS directly
+// (WM*16*MT) x (64*WN) output tile, BK = 64, WM x WN waves, each wave
+// (16*MT) tokens x 64 features = MT x 4 MFMA tiles; the launcher picks
+// 64 x 128 or 128 x 128 with eight waves.  Operands go global -> LDS directly
 // (global_load_lds_dwordx4: no VGPR staging, 1 KiB per wave instruction) into a
 // double-buffered image whose 16-byte chunks are XOR-swizzled by the row
 // (chunk ^= row & 7): the DMA writes LDS linearly, so the permutation is applied
 // to the per-lane SOURCE address, and again on the fragment reads, which makes
 // every ds_read_b128 of the 16x16x32 operand maps bank-conflict free.
-constexpr int BN = 128, BK = 64;
-constexpr int W_ELEMS = BN * BK;  // weight slab per buffer (16 KiB)
+constexpr int BK = 64;
 
 enum { EPI_BF16 = 0, EPI_GELU = 1, EPI_QUICKGELU = 2, EPI_RESID = 3,
        EPI_AFFINE = 4, EPI_AFFINE_RELU = 5 };
@@ -105,39 +104,44 @@ __device__ __forceinline__ float quick_gelu(float x) {
 }
 
 
-template <int EPI, int MT>
-__global__ __launch_bounds__(256) void k_gemm_bf16(
+template <int EPI, int WM, int WN, int MT>
+__global__ __launch_bounds__(64 * WM * WN) void k_gemm_bf16(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
     const float* __restrict__ bias, const float* __restrict__ gamma,
     float* __restrict__ resid, bf16_t* __restrict__ out, int M, int N, int K) {
   // one array for all staging (a second __shared__ object beside a DMA target
   // can make hipcc drain vmcnt before every ds_read: guide section 5 item 4a)
-  constexpr int BM = 32 * MT;           // tile height
+  constexpr int BM = WM * 16 * MT;      // tile height
+  constexpr int TBN = 64 * WN;          // tile width
+  constexpr int NW = WM * WN;           // waves
   constexpr int A_ELEMS = BM * BK;      // activation slab per buffer
-  constexpr int BUF_ELEMS = A_ELEMS + W_ELEMS;
+  constexpr int TW_ELEMS = TBN * BK;    // weight slab per buffer
+  constexpr int BUF_ELEMS = A_ELEMS + TW_ELEMS;
+  constexpr int APIECES = BM / 8, WPIECES = TBN / 8;  // 1 KiB DMA pieces
+  constexpr int AP = (APIECES + NW - 1) / NW, WP = (WPIECES + NW - 1) / NW;
   extern __shared__ __attribute__((aligned(16))) bf16_t smem[];  // [2][A|W]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int wm = wave / WN, wn = wave % WN;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * TBN;
   const int fr = lane & 15, fg = lane >> 4;
 
-  // DMA map: a wave instruction fills 64 LDS chunks = 8 rows of a slab; wave w
-  // issues pieces w*MT .. +MT of the activation slab (BM/8 = 4*MT pieces) and
-  // w*4 .. +4 of the weight slab; lane l lands in row r = 8*piece + l/8, physical
-  // chunk l%8, so it must fetch logical chunk (l%8) ^ (r&7).  Rows beyond M / N
-  // are clamped (their outputs are dropped).
-  const bf16_t* srcA[MT];
-  const bf16_t* srcW[4];
+  // DMA map: a wave instruction fills 64 LDS chunks = 8 rows of a slab; the
+  // pieces of each slab are dealt round-robin to the waves (wave w issues pieces
+  // w, w + NW, ...); lane l lands in row r = 8*piece + l/8, physical chunk l%8,
+  // so it must fetch logical chunk (l%8) ^ (r&7).  Rows beyond M / N are
+  // clamped (their outputs are dropped).
+  const bf16_t* srcA[AP];
+  const bf16_t* srcW[WP];
 #pragma unroll
-  for (int j = 0; j < MT; ++j) {
-    const int r = (wave * MT + j) * 8 + (lane >> 3);
+  for (int j = 0; j < AP; ++j) {
+    const int r = (wave + j * NW) * 8 + (lane >> 3);
     const int c = (lane & 7) ^ (r & 7);
     const int gm = m0 + r < M ? m0 + r : M - 1;
     srcA[j] = A + (int64_t)gm * K + c * 8;
   }
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int r = (wave * 4 + j) * 8 + (lane >> 3);
+  for (int j = 0; j < WP; ++j) {
+    const int r = (wave + j * NW) * 8 + (lane >> 3);
     const int c = (lane & 7) ^ (r & 7);
     const int gn = n0 + r < N ? n0 + r : N - 1;
     srcW[j] = W + (int64_t)gn * K + c * 8;
@@ -146,13 +150,15 @@ __global__ __launch_bounds__(256) void k_gemm_bf16(
     bf16_t* dA = smem + buf * BUF_ELEMS;
     bf16_t* dW = dA + A_ELEMS;
 #pragma unroll
-    for (int j = 0; j < MT; ++j)
-      __builtin_amdgcn_global_load_lds((gptr_t)(srcA[j] + k0),
-                                       (lptr_t)(dA + (wave * MT + j) * 512), 16, 0, 0);
+    for (int j = 0; j < AP; ++j)
+      if (wave + j * NW < APIECES)  // wave-uniform
+        __builtin_amdgcn_global_load_lds((gptr_t)(srcA[j] + k0),
+                                         (lptr_t)(dA + (wave + j * NW) * 512), 16, 0, 0);
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-      __builtin_amdgcn_global_load_lds((gptr_t)(srcW[j] + k0),
-                                       (lptr_t)(dW + (wave * 4 + j) * 512), 16, 0, 0);
+    for (int j = 0; j < WP; ++j)
+      if (wave + j * NW < WPIECES)
+        __builtin_amdgcn_global_load_lds((gptr_t)(srcW[j] + k0),
+                                         (lptr_t)(dW + (wave + j * NW) * 512), 16, 0, 0);
   };
 
   f32x4 acc[MT][4];  // [token tile][feature tile]
@@ -531,28 +537,33 @@ int veon_vit_gemm(const void* a_bf16, const void* w_bf16, const float* bias,
   const bf16_t* A = static_cast<const bf16_t*>(a_bf16);
   const bf16_t* W = static_cast<const bf16_t*>(w_bf16);
   bf16_t* O = static_cast<bf16_t*>(out_bf16);
-  // tile height: 64 rows (3 workgroups per CU by LDS) unless that makes more
-  // than ~8 workgroups per CU, where the 128-row tile's halved weight traffic
-  // wins.  Measured at M = 5406 (profiles/r01_vit_bench.txt): these GEMMs are
-  // latency/occupancy-bound, not round-quantisation-bound -- 160/192-row tiles
-  // that bring N = 768 down to one round of workgroups were 20 % slower.
-  const int64_t ncol = (N + BN - 1) / BN;
-  const int mt = ((int64_t)((M + 63) / 64) * ncol > 8 * kNumCU) ? 4 : 2;
-  const dim3 grid((unsigned)ncol, (unsigned)((M + 32 * mt - 1) / (32 * mt)));
-#define VEON_LAUNCH_GEMM(EPI, MT)                                              \
+  // Tile: 64 x 128 with EIGHT waves of 16 x 64 (3 workgroups per CU by LDS, 24
+  // waves per CU) unless that makes more than ~8 workgroups per CU, where the
+  // 128-row tile's halved weight traffic wins.  Measured at M = 5406
+  // (profiles/r01_vit_bench.txt): these GEMMs are latency/occupancy-bound --
+  // more, smaller waves beat the 4-wave tiles of the same size by 5-10 %,
+  // 256-wide 16-wave tiles and 160/192-row tiles that bring N = 768 down to one
+  // round of workgroups were 10-20 % slower.
+  const int wm = 4, wn = 2;
+  const int mt = ((int64_t)((M + 63) / 64) * ((N + 127) / 128) > 8 * kNumCU) ? 2 : 1;
+  const int bm = wm * 16 * mt, bn = 64 * wn;
+  const dim3 grid((unsigned)((N + bn - 1) / bn), (unsigned)((M + bm - 1) / bm));
+#define VEON_LAUNCH_GEMM(EPI, WM, WN, MT)                                      \
   do {                                                                         \
-    constexpr int lds = 2 * (32 * MT * BK + W_ELEMS) * (int)sizeof(bf16_t);    \
+    constexpr int lds = 2 * (WM * 16 * MT + 64 * WN) * BK * (int)sizeof(bf16_t); \
     static const hipError_t attr = hipFuncSetAttribute(                        \
-        reinterpret_cast<const void*>(&k_gemm_bf16<EPI, MT>),                  \
+        reinterpret_cast<const void*>(&k_gemm_bf16<EPI, WM, WN, MT>),          \
         hipFuncAttributeMaxDynamicSharedMemorySize, lds);                      \
     if (attr != hipSuccess) return VEON_ERR_LAUNCH;                            \
-    hipLaunchKernelGGL((k_gemm_bf16<EPI, MT>), grid, dim3(256), lds, s, A, W,  \
-                       bias, gamma, resid, O, M, N, K);                        \
+    hipLaunchKernelGGL((k_gemm_bf16<EPI, WM, WN, MT>), grid,                   \
+                       dim3(64 * WM * WN), lds, s, A, W, bias, gamma, resid,   \
+                       O, M, N, K);                                            \
   } while (0)
+#define VEON_T(a, b, c) (wm == a && wn == b && mt == c)
 #define VEON_LAUNCH_GEMM_MT(EPI)                                               \
   do {                                                                         \
-    if (mt == 4) VEON_LAUNCH_GEMM(EPI, 4);                                     \
-    else VEON_LAUNCH_GEMM(EPI, 2);                                             \
+    if (VEON_T(4, 2, 2)) VEON_LAUNCH_GEMM(EPI, 4, 2, 2);                       \
+    else VEON_LAUNCH_GEMM(EPI, 4, 2, 1);                                       \
   } while (0)
   switch (epilogue) {
     case EPI_BF16: VEON_LAUNCH_GEMM_MT(EPI_BF16); break;
@@ -564,6 +575,7 @@ int veon_vit_gemm(const void* a_bf16, const void* w_bf16, const float* bias,
     default: return VEON_ERR_BAD_ARG;
   }
 #undef VEON_LAUNCH_GEMM_MT
+#undef VEON_T
 #undef VEON_LAUNCH_GEMM
   return launch_status();
 }
