@@ -347,6 +347,23 @@ int veon_conv3d_k3_bf16(const void *in_padded, const void *w_bf16,
                         const float *scale, const float *shift,
                         const void *resid_padded, void *out_padded, int B, int Z,
                         int Y, int X, int Cin, int Cout, int relu, void *stream);
+/*
+ * The 2-D case: 3x3 stride-1 pad-1 convolution on images in the padded
+ * channels-last bf16 grid [B][Y+2][X+2][C] (no z halo), same kernel with 9 taps,
+ * same epilogue, same guard-row contract.  w: [Cout][3][3][Cin] bf16.  Used for
+ * the 3x3 convolutions of DepthAnythingV2's DPT head
+ * (mmdet3d/models/depth_anything/dpt.py:39-150, util/blocks.py) when the head
+ * runs in bf16.
+ */
+int veon_conv2d_k3_bf16(const void *in_padded, const void *w_bf16,
+                        const float *scale, const float *shift,
+                        const void *resid_padded, void *out_padded, int B, int Y,
+                        int X, int Cin, int Cout, int relu, void *stream);
+/* (B,C,Y,X) fp32 or bf16 (nchw_is_bf16) <-> interior of the padded image grid */
+int veon_image_pack_bf16(const void *nchw, int nchw_is_bf16, void *padded, int B,
+                         int C, int Y, int X, void *stream);
+int veon_image_unpack(const void *padded, void *nchw, int nchw_is_bf16, int B,
+                      int C, int Y, int X, void *stream);
 /* (B,C,Z,Y,X) fp32 <-> interior of the padded channels-last bf16 grid (the halo
  * is not touched: allocate the grid zeroed once). */
 int veon_volume_pack_bf16(const float *ncdhw, void *padded, int B, int C, int Z,

@@ -220,3 +220,38 @@ def test_hip_body_and_heads_against_reference_vectors():
         want = torch.from_numpy(g[key])
         rel = ((got.cpu() - want).norm() / want.norm()).item()
         assert rel < tol, (key, rel)
+
+
+@pytest.mark.parametrize('B,Cin,Cout,Y,X', [(1, 64, 64, 5, 7), (2, 128, 128, 9, 33),
+                                           (1, 64, 32, 20, 41), (6, 128, 64, 36, 50)])
+@pytest.mark.parametrize('mode', ['bias', 'bias_relu', 'bias_resid'])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_conv2d_matches_torch(B, Cin, Cout, Y, X, mode, dtype):
+    """The 2-D (9-tap) mode of the conv kernel, incl. the 64-wide tiles and the
+    bf16 planar pack / unpack used by the DPT head."""
+    if mode == 'bias_resid' and Cin != Cout:
+        pytest.skip('identity add needs Cin == Cout')
+    g = torch.Generator().manual_seed(Cin * 7 + Cout + X)
+    x = _bf(torch.randn(B, Cin, Y, X, generator=g)).to(DEV)
+    w = _bf(torch.randn(Cout, Cin, 3, 3, generator=g) * (9 * Cin) ** -0.5).to(DEV)
+    bias = torch.randn(Cout, generator=g).to(DEV)
+    want = F.conv2d(x.double(), w.double(), bias.double(), padding=1).float()
+    img = conv3d_ops.pack_image(x.to(dtype))
+    wp = conv3d_ops.pack_weight2d(w)
+    shift = torch.zeros(wp.shape[0], device=DEV)
+    shift[:Cout] = bias
+    if mode == 'bias':
+        out = conv3d_ops.conv2d_k3(img, wp, None, shift)
+    elif mode == 'bias_relu':
+        want = F.relu(want)
+        out = conv3d_ops.conv2d_k3(img, wp, None, shift, relu=True)
+    else:
+        want = want + x
+        out = conv3d_ops.conv2d_k3(img, wp, None, shift, resid=img)
+    got = conv3d_ops.unpack_image(out, dtype, channels=Cout).float()
+    if dtype == torch.bfloat16:
+        assert torch.equal(got, conv3d_ops.unpack_image(out, torch.float32, Cout))
+    _close(got, want)
+    grid = out.rows.view(B, Y + 2, X + 2, -1).float().clone()
+    grid[:, 1:-1, 1:-1] = 0
+    assert float(grid.abs().sum()) == 0.0

@@ -60,6 +60,9 @@ _SIGNATURES = {
     'veon_vit_block': (_ci, [_vp, _vp, _vp, _i64, _i64, _vp, _i64] + [_ci] * 4 + [_vp]),
     'veon_conv3d_guard_rows': (_i64, [_ci, _ci]),
     'veon_conv3d_k3_bf16': (_ci, [_vp] * 6 + [_ci] * 7 + [_vp]),
+    'veon_conv2d_k3_bf16': (_ci, [_vp] * 6 + [_ci] * 6 + [_vp]),
+    'veon_image_pack_bf16': (_ci, [_vp, _ci, _vp] + [_ci] * 4 + [_vp]),
+    'veon_image_unpack': (_ci, [_vp, _vp, _ci] + [_ci] * 4 + [_vp]),
     'veon_volume_pack_bf16': (_ci, [_vp, _vp] + [_ci] * 5 + [_vp]),
     'veon_volume_unpack_f32': (_ci, [_vp, _vp] + [_ci] * 5 + [_vp]),
     'veon_camera_matrices': (_ci, [_ci] + [_vp] * 6 + [_vp]),

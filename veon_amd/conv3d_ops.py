@@ -94,3 +94,87 @@ def conv3d_k3(vol, w_packed, scale=None, shift=None, resid=None, relu=False,
             _lib.stream_ptr(dev))
     _lib.check(st, 'veon_conv3d_k3_bf16')
     return out
+
+
+# ----------------------------------------------------------------- 2-D images
+class PaddedImage:
+    """(B,C,Y,X) images as a zero-haloed channels-last bf16 grid
+    [B][Y+2][X+2][C] (+ guard rows), the 2-D twin of ``PaddedVolume``."""
+
+    def __init__(self, B, C, Y, X, device):
+        self.shape = (int(B), int(C), int(Y), int(X))
+        B, C, Y, X = self.shape
+        self.guard = int(_lib.lib().veon_conv3d_guard_rows(Y, X))
+        self.M = B * (Y + 2) * (X + 2)
+        self.storage = torch.zeros((self.M + 2 * self.guard, C),
+                                   dtype=torch.bfloat16, device=device)
+        self.rows = self.storage[self.guard:self.guard + self.M]
+
+    @property
+    def device(self):
+        return self.storage.device
+
+
+def pack_image(x, out=None):
+    """(B,C,H,W) fp32 or bf16 -> PaddedImage."""
+    dev = _lib.require_device(x)
+    if x.dtype not in (torch.float32, torch.bfloat16):
+        x = x.float()
+    x = x.contiguous()
+    B, C, Y, X = x.shape
+    if out is None:
+        out = PaddedImage(B, C, Y, X, dev)
+    assert out.shape == tuple(x.shape)
+    with torch.cuda.device(dev):
+        st = _lib.lib().veon_image_pack_bf16(
+            _lib.ptr(x), 1 if x.dtype == torch.bfloat16 else 0, _lib.ptr(out.rows),
+            B, C, Y, X, _lib.stream_ptr(dev))
+    _lib.check(st, 'veon_image_pack_bf16')
+    return out
+
+
+def unpack_image(img, dtype=torch.float32, channels=None):
+    """PaddedImage -> (B,C,H,W) fp32 or bf16 (first ``channels`` channels)."""
+    dev = _lib.require_device(img.storage)
+    B, C, Y, X = img.shape
+    out = torch.empty(img.shape, dtype=dtype, device=dev)
+    with torch.cuda.device(dev):
+        st = _lib.lib().veon_image_unpack(
+            _lib.ptr(img.rows), _lib.ptr(out), 1 if dtype == torch.bfloat16 else 0,
+            B, C, Y, X, _lib.stream_ptr(dev))
+    _lib.check(st, 'veon_image_unpack')
+    return out if channels is None else out[:, :channels]
+
+
+def pack_weight2d(w, pad_out_to=8):
+    """nn.Conv2d weight (Cout,Cin,3,3) -> bf16 [Cout'][3][3][Cin], Cout padded
+    with zero filters to a multiple of ``pad_out_to``."""
+    assert w.dim() == 4 and tuple(w.shape[2:]) == (3, 3)
+    cout = w.shape[0]
+    npad = (cout + pad_out_to - 1) // pad_out_to * pad_out_to
+    wp = torch.zeros((npad,) + tuple(w.shape[1:]), dtype=torch.float32, device=w.device)
+    wp[:cout] = w.detach().float()
+    return wp.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16)
+
+
+def conv2d_k3(img, w_packed, scale=None, shift=None, resid=None, relu=False,
+              out=None):
+    """3x3 stride-1 pad-1 convolution on a PaddedImage with the fused epilogue
+    ``relu?(conv*scale + shift + resid?)`` -> PaddedImage."""
+    dev = _lib.require_device(img.storage, w_packed)
+    B, Cin, Y, X = img.shape
+    Cout = w_packed.shape[0]
+    assert w_packed.dtype == torch.bfloat16 and w_packed.is_contiguous()
+    assert w_packed.numel() == Cout * 9 * Cin
+    if out is None:
+        out = PaddedImage(B, Cout, Y, X, dev)
+    assert out.shape == (B, Cout, Y, X) and out is not img
+    if resid is not None:
+        assert resid.shape == out.shape
+    with torch.cuda.device(dev):
+        st = _lib.lib().veon_conv2d_k3_bf16(
+            _lib.ptr(img.rows), _lib.ptr(w_packed), _lib.ptr(scale), _lib.ptr(shift),
+            _lib.ptr(None if resid is None else resid.rows), _lib.ptr(out.rows),
+            B, Y, X, Cin, Cout, 1 if relu else 0, _lib.stream_ptr(dev))
+    _lib.check(st, 'veon_conv2d_k3_bf16')
+    return out

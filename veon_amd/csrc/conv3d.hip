@@ -34,7 +34,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv3d_k3(
     const bf16_t* __restrict__ in, const bf16_t* __restrict__ W,
     const float* __restrict__ scale, const float* __restrict__ shift,
     const bf16_t* __restrict__ resid, bf16_t* __restrict__ out, int planes,
-    int Zp, int Yp, int Xp, int Cin, int Cout) {
+    int Zp, int Yp, int Xp, int Cin, int Cout, int kd) {
   constexpr int BM = WM * 16 * MT;
   constexpr int CBN = 64 * WN;
   constexpr int NW = WM * WN;              // waves
@@ -54,10 +54,13 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv3d_k3(
   const int YX = Yp * Xp;
   const int M = planes * YX;  // planes = B * Zp
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * CBN;
-  const int K = 27 * Cin;
+  // kd = 3: 3x3x3 taps on a grid padded in z, y and x; kd = 1: the 2-D case,
+  // 3x3 taps on [B][Yp][Xp] images (Zp = planes per image = 1, no z halo)
+  const int ntaps = 9 * kd;
+  const int K = ntaps * Cin;
 
   // tile entirely inside z-halo planes: nothing to contract, store zeros
-  {
+  if (kd == 3) {
     const int p0 = m0 / YX;
     const int mlast = (m0 + BM - 1 < M ? m0 + BM - 1 : M - 1);
     const int p1 = mlast / YX;
@@ -98,8 +101,8 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv3d_k3(
   auto a_off = [&](int kt) -> int64_t {
     const int tap = kt / cpk;
     const int cc = (kt - tap * cpk) * CBK;
-    const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
-    const int off = ((dz - 1) * Yp + (dy - 1)) * Xp + (dx - 1);
+    const int dz = kd == 3 ? tap / 9 - 1 : 0, dy = (tap / 3) % 3, dx = tap % 3;
+    const int off = (dz * Yp + (dy - 1)) * Xp + (dx - 1);
     return (int64_t)off * Cin + cc;
   };
   auto dma = [&](int buf, int kt) {
@@ -136,7 +139,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv3d_k3(
     offW[i] = rw * CBK + ((fg ^ (rw & 7)) * 8);
   }
 
-  const int nk = 27 * cpk;
+  const int nk = ntaps * cpk;
   auto compute = [&](int buf) {
     const bf16_t* tA = smem + buf * BUF_ELEMS;
     const bf16_t* tW = tA + A_ELEMS;
@@ -174,8 +177,8 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv3d_k3(
     if (m >= M) continue;
     const int p = m / YX, rem = m - p * YX;
     const int y = rem / Xp, x = rem - y * Xp, z = p % Zp;
-    const bool interior = z >= 1 && z <= Zp - 2 && y >= 1 && y <= Yp - 2 &&
-                          x >= 1 && x <= Xp - 2;
+    const bool interior = (kd == 1 || (z >= 1 && z <= Zp - 2)) && y >= 1 &&
+                          y <= Yp - 2 && x >= 1 && x <= Xp - 2;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int n = n0 + wn * 64 + j * 16 + fg * 4;
@@ -206,11 +209,22 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv3d_k3(
   }
 }
 
-// (B,C,Z,Y,X) fp32 -> interior of the padded channels-last bf16 grid.  One
-// workgroup = one (b,z,y) row x 64 channels: reads are x-contiguous per channel,
-// writes are channel-contiguous per voxel, transposed through LDS.
+// Planar (B,C,Z,Y,X) fp32 or bf16 -> interior of the padded channels-last bf16
+// grid.  One workgroup = one (b,z,y) row x 64 channels: reads are x-contiguous per
+// channel, writes channel-contiguous per voxel, transposed through LDS.  PZ = 1:
+// the grid is padded in z too (3-D volumes); PZ = 0: images, [B*Z][Y+2][X+2][C].
+template <typename TP>
+__device__ __forceinline__ float planar_load(const TP* p);
+template <>
+__device__ __forceinline__ float planar_load<float>(const float* p) { return *p; }
+template <>
+__device__ __forceinline__ float planar_load<bf16_t>(const bf16_t* p) { return bf2f(*p); }
+__device__ __forceinline__ void planar_store(float* p, float v) { *p = v; }
+__device__ __forceinline__ void planar_store(bf16_t* p, float v) { *p = f2bf(v); }
+
+template <typename TP, int PZ>
 __global__ __launch_bounds__(256) void k_volume_pack(
-    const float* __restrict__ in, bf16_t* __restrict__ out, int C, int Z, int Y,
+    const TP* __restrict__ in, bf16_t* __restrict__ out, int C, int Z, int Y,
     int X) {
   __shared__ float t[64][65];
   const int Yp = Y + 2, Xp = X + 2;
@@ -219,12 +233,13 @@ __global__ __launch_bounds__(256) void k_volume_pack(
   const int c0 = blockIdx.y * 64;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int64_t cstride = (int64_t)Z * Y * X;
-  const float* ib = in + ((int64_t)b * C) * cstride + ((int64_t)z * Y + y) * X;
-  bf16_t* ob = out + ((((int64_t)b * (Z + 2) + z + 1) * Yp + y + 1) * Xp + 1) * C;
+  const TP* ib = in + ((int64_t)b * C) * cstride + ((int64_t)z * Y + y) * X;
+  bf16_t* ob =
+      out + ((((int64_t)b * (Z + 2 * PZ) + z + PZ) * Yp + y + 1) * Xp + 1) * C;
   for (int x0 = 0; x0 < X; x0 += 64) {
     for (int cc = ty; cc < 64; cc += 4)
       t[cc][tx] = (x0 + tx < X && c0 + cc < C)
-                      ? ib[(int64_t)(c0 + cc) * cstride + x0 + tx]
+                      ? planar_load<TP>(ib + (int64_t)(c0 + cc) * cstride + x0 + tx)
                       : 0.f;
     __syncthreads();
     for (int xx = ty; xx < 64; xx += 4)
@@ -234,9 +249,10 @@ __global__ __launch_bounds__(256) void k_volume_pack(
   }
 }
 
-// interior of the padded channels-last bf16 grid -> (B,C,Z,Y,X) fp32
+// interior of the padded channels-last bf16 grid -> planar (B,C,Z,Y,X)
+template <typename TP, int PZ>
 __global__ __launch_bounds__(256) void k_volume_unpack(
-    const bf16_t* __restrict__ in, float* __restrict__ out, int C, int Z, int Y,
+    const bf16_t* __restrict__ in, TP* __restrict__ out, int C, int Z, int Y,
     int X) {
   __shared__ float t[64][65];
   const int Yp = Y + 2, Xp = X + 2;
@@ -245,9 +261,9 @@ __global__ __launch_bounds__(256) void k_volume_unpack(
   const int c0 = blockIdx.y * 64;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int64_t cstride = (int64_t)Z * Y * X;
-  float* ob = out + ((int64_t)b * C) * cstride + ((int64_t)z * Y + y) * X;
+  TP* ob = out + ((int64_t)b * C) * cstride + ((int64_t)z * Y + y) * X;
   const bf16_t* ib =
-      in + ((((int64_t)b * (Z + 2) + z + 1) * Yp + y + 1) * Xp + 1) * C;
+      in + ((((int64_t)b * (Z + 2 * PZ) + z + PZ) * Yp + y + 1) * Xp + 1) * C;
   for (int x0 = 0; x0 < X; x0 += 64) {
     for (int xx = ty; xx < 64; xx += 4)
       t[xx][tx] = (x0 + xx < X && c0 + tx < C)
@@ -256,7 +272,7 @@ __global__ __launch_bounds__(256) void k_volume_unpack(
     __syncthreads();
     for (int cc = ty; cc < 64; cc += 4)
       if (x0 + tx < X && c0 + cc < C)
-        ob[(int64_t)(c0 + cc) * cstride + x0 + tx] = t[tx][cc];
+        planar_store(ob + (int64_t)(c0 + cc) * cstride + x0 + tx, t[tx][cc]);
     __syncthreads();
   }
 }
@@ -271,10 +287,11 @@ int64_t veon_conv3d_guard_rows(int Y, int X) {
   return (int64_t)(Y + 2) * (X + 2) + (X + 2) + 1 + 512;
 }
 
-int veon_conv3d_k3_bf16(const void* in_padded, const void* w_bf16,
+static int conv_k3_impl(int kd, const void* in_padded, const void* w_bf16,
                         const float* scale, const float* shift,
                         const void* resid_padded, void* out_padded, int B, int Z,
                         int Y, int X, int Cin, int Cout, int relu, void* stream) {
+  const int pz = kd == 3 ? 1 : 0;  // z halo planes on each side
   if (B <= 0 || Z <= 0 || Y <= 0 || X <= 0 || Cin <= 0 || Cout <= 0 ||
       Cin % CBK != 0 || Cout % 8 != 0 || !in_padded || !w_bf16 || !out_padded)
     return VEON_ERR_BAD_ARG;
@@ -282,7 +299,7 @@ int veon_conv3d_k3_bf16(const void* in_padded, const void* w_bf16,
       (scale && !al16(scale)) || (shift && !al16(shift)) ||
       (resid_padded && !al16(resid_padded)))
     return VEON_ERR_BAD_ARG;
-  const int64_t M = (int64_t)B * (Z + 2) * (Y + 2) * (X + 2);
+  const int64_t M = (int64_t)B * (Z + 2 * pz) * (Y + 2) * (X + 2);
   if (M > 0x3fffffffLL) return VEON_ERR_BAD_ARG;
   // Tile choice.  256 features wide when the layer has them (the activation
   // slab is then fetched once, not once per 128-feature column); the height is
@@ -293,8 +310,9 @@ int veon_conv3d_k3_bf16(const void* in_padded, const void* w_bf16,
   struct Tile { int wm, wn, mt; };
   static const Tile wide[] = {{4, 4, 3}, {4, 4, 4}, {3, 4, 7}};   // 192/256/336 x 256
   static const Tile narrow[] = {{4, 2, 1}, {4, 2, 2}};             // 64/128 x 128, 8 waves
+  static const Tile slim[] = {{8, 1, 1}, {8, 1, 2}};               // 128/256 x 64, 8 waves
   const bool is_wide = Cout >= 256;
-  const Tile* cands = is_wide ? wide : narrow;
+  const Tile* cands = is_wide ? wide : (Cout <= 64 ? slim : narrow);
   const int ncand = is_wide ? 3 : 2;
   const int64_t active = (int64_t)B * Z * (Y + 2) * (X + 2);  // rows off the z-halo
   int wm = cands[0].wm, wn = cands[0].wn, mt = cands[0].mt;
@@ -318,7 +336,7 @@ int veon_conv3d_k3_bf16(const void* in_padded, const void* w_bf16,
   const bf16_t* Wt = static_cast<const bf16_t*>(w_bf16);
   const bf16_t* R = static_cast<const bf16_t*>(resid_padded);
   bf16_t* O = static_cast<bf16_t*>(out_padded);
-  const int planes = B * (Z + 2);
+  const int planes = B * (Z + 2 * pz);
 #define VEON_LAUNCH_CONV(WM, WN, MT, RELU, RESID)                              \
   do {                                                                         \
     constexpr int lds =                                                        \
@@ -329,7 +347,7 @@ int veon_conv3d_k3_bf16(const void* in_padded, const void* w_bf16,
     if (attr != hipSuccess) return VEON_ERR_LAUNCH;                            \
     hipLaunchKernelGGL((k_conv3d_k3<WM, WN, MT, RELU, RESID>), grid,           \
                        dim3(64 * WM * WN), lds, s, I, Wt, scale, shift, R, O,  \
-                       planes, Z + 2, Y + 2, X + 2, Cin, Cout);                \
+                       planes, Z + 2 * pz, Y + 2, X + 2, Cin, Cout, kd);       \
   } while (0)
 #define VEON_TILE_IS(a, b, c) (wm == a && wn == b && mt == c)
 #define VEON_LAUNCH_CONV_T(RELU, RESID)                                        \
@@ -338,6 +356,8 @@ int veon_conv3d_k3_bf16(const void* in_padded, const void* w_bf16,
     else if (VEON_TILE_IS(4, 4, 3)) VEON_LAUNCH_CONV(4, 4, 3, RELU, RESID);    \
     else if (VEON_TILE_IS(4, 4, 4)) VEON_LAUNCH_CONV(4, 4, 4, RELU, RESID);    \
     else if (VEON_TILE_IS(4, 2, 2)) VEON_LAUNCH_CONV(4, 2, 2, RELU, RESID);    \
+    else if (VEON_TILE_IS(8, 1, 1)) VEON_LAUNCH_CONV(8, 1, 1, RELU, RESID);    \
+    else if (VEON_TILE_IS(8, 1, 2)) VEON_LAUNCH_CONV(8, 1, 2, RELU, RESID);    \
     else VEON_LAUNCH_CONV(4, 2, 1, RELU, RESID);                               \
   } while (0)
   if (relu) {
@@ -351,29 +371,70 @@ int veon_conv3d_k3_bf16(const void* in_padded, const void* w_bf16,
   return launch_status();
 }
 
-int veon_volume_pack_bf16(const float* ncdhw, void* padded, int B, int C, int Z,
-                          int Y, int X, void* stream) {
-  if (B <= 0 || C <= 0 || Z <= 0 || Y <= 0 || X <= 0 || !ncdhw || !padded)
+int veon_conv3d_k3_bf16(const void* in_padded, const void* w_bf16,
+                        const float* scale, const float* shift,
+                        const void* resid_padded, void* out_padded, int B, int Z,
+                        int Y, int X, int Cin, int Cout, int relu, void* stream) {
+  return conv_k3_impl(3, in_padded, w_bf16, scale, shift, resid_padded, out_padded,
+                      B, Z, Y, X, Cin, Cout, relu, stream);
+}
+
+int veon_conv2d_k3_bf16(const void* in_padded, const void* w_bf16,
+                        const float* scale, const float* shift,
+                        const void* resid_padded, void* out_padded, int B, int Y,
+                        int X, int Cin, int Cout, int relu, void* stream) {
+  return conv_k3_impl(1, in_padded, w_bf16, scale, shift, resid_padded, out_padded,
+                      B, 1, Y, X, Cin, Cout, relu, stream);
+}
+
+static int pack_impl(bool unpack, int pz, int planar_bf16, const void* planar,
+                     const void* padded, int B, int C, int Z, int Y, int X,
+                     void* stream) {
+  if (B <= 0 || C <= 0 || Z <= 0 || Y <= 0 || X <= 0 || !planar || !padded)
     return VEON_ERR_BAD_ARG;
   const int64_t rows = (int64_t)B * Z * Y;
   if (rows > 0x7fffffffLL) return VEON_ERR_BAD_ARG;
-  hipLaunchKernelGGL(k_volume_pack, dim3((unsigned)rows, (unsigned)((C + 63) / 64)),
-                     dim3(256), 0, static_cast<hipStream_t>(stream), ncdhw,
-                     static_cast<bf16_t*>(padded), C, Z, Y, X);
+  const dim3 grid((unsigned)rows, (unsigned)((C + 63) / 64));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+#define VEON_PACK(TP, PZ)                                                       \
+  do {                                                                          \
+    if (unpack)                                                                 \
+      hipLaunchKernelGGL((k_volume_unpack<TP, PZ>), grid, dim3(256), 0, s,      \
+                         static_cast<const bf16_t*>(padded),                    \
+                         static_cast<TP*>(const_cast<void*>(planar)), C, Z, Y, X); \
+    else                                                                        \
+      hipLaunchKernelGGL((k_volume_pack<TP, PZ>), grid, dim3(256), 0, s,        \
+                         static_cast<const TP*>(planar),                        \
+                         static_cast<bf16_t*>(const_cast<void*>(padded)), C, Z, \
+                         Y, X);                                                 \
+  } while (0)
+  if (planar_bf16) {
+    if (pz) VEON_PACK(bf16_t, 1); else VEON_PACK(bf16_t, 0);
+  } else {
+    if (pz) VEON_PACK(float, 1); else VEON_PACK(float, 0);
+  }
+#undef VEON_PACK
   return launch_status();
+}
+
+int veon_volume_pack_bf16(const float* ncdhw, void* padded, int B, int C, int Z,
+                          int Y, int X, void* stream) {
+  return pack_impl(false, 1, 0, ncdhw, padded, B, C, Z, Y, X, stream);
 }
 
 int veon_volume_unpack_f32(const void* padded, float* ncdhw, int B, int C, int Z,
                            int Y, int X, void* stream) {
-  if (B <= 0 || C <= 0 || Z <= 0 || Y <= 0 || X <= 0 || !ncdhw || !padded)
-    return VEON_ERR_BAD_ARG;
-  const int64_t rows = (int64_t)B * Z * Y;
-  if (rows > 0x7fffffffLL) return VEON_ERR_BAD_ARG;
-  hipLaunchKernelGGL(k_volume_unpack,
-                     dim3((unsigned)rows, (unsigned)((C + 63) / 64)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream),
-                     static_cast<const bf16_t*>(padded), ncdhw, C, Z, Y, X);
-  return launch_status();
+  return pack_impl(true, 1, 0, ncdhw, padded, B, C, Z, Y, X, stream);
+}
+
+int veon_image_pack_bf16(const void* nchw, int nchw_is_bf16, void* padded, int B,
+                         int C, int Y, int X, void* stream) {
+  return pack_impl(false, 0, nchw_is_bf16, nchw, padded, B, C, 1, Y, X, stream);
+}
+
+int veon_image_unpack(const void* padded, void* nchw, int nchw_is_bf16, int B,
+                      int C, int Y, int X, void* stream) {
+  return pack_impl(true, 0, nchw_is_bf16, nchw, padded, B, C, 1, Y, X, stream);
 }
 
 }  // extern "C"
