@@ -129,7 +129,7 @@ def bench_hotpath(args, rank, world, dev, dist):
         'ms_per_step': round(ms, 4), 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
         'config': {'workload': 'VEONB: 6-cam 256x704 -> DA-V2 ViT-B (MFMA encoder, DPT head '
-                               'PyTorch/MIOpen bf16) + CLIP ViT-B/16 trunk (MFMA) + sync-free '
+                               'bf16 with its 3x3 convs on the MFMA conv kernel) + CLIP ViT-B/16 trunk (MFMA) + sync-free '
                                'lift (D=88, C=256, 200x200x16, fused 2x2x2 max-pool) + 4x '
                                'ResBlock3D body + occ/sem heads (MFMA); random weights; SAN side '
                                'adapter / HSA / upsample / classifier not included',

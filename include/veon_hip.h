@@ -364,6 +364,11 @@ int veon_image_pack_bf16(const void *nchw, int nchw_is_bf16, void *padded, int B
                          int C, int Y, int X, void *stream);
 int veon_image_unpack(const void *padded, void *nchw, int nchw_is_bf16, int B,
                       int C, int Y, int X, void *stream);
+/* F.interpolate(mode='bilinear', align_corners=True) between two padded images
+ * (interior written only; C % 8 == 0). */
+int veon_image_resize_bilinear(const void *in_padded, void *out_padded, int B,
+                               int C, int Yi, int Xi, int Yo, int Xo,
+                               void *stream);
 /* (B,C,Z,Y,X) fp32 <-> interior of the padded channels-last bf16 grid (the halo
  * is not touched: allocate the grid zeroed once). */
 int veon_volume_pack_bf16(const float *ncdhw, void *padded, int B, int C, int Z,

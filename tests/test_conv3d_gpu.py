@@ -255,3 +255,19 @@ def test_conv2d_matches_torch(B, Cin, Cout, Y, X, mode, dtype):
     grid = out.rows.view(B, Y + 2, X + 2, -1).float().clone()
     grid[:, 1:-1, 1:-1] = 0
     assert float(grid.abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize('size_in,size_out', [((4, 6), (8, 12)), ((9, 25), (18, 50)),
+                                              ((144, 400), (252, 700)), ((5, 5), (1, 1))])
+def test_resize_bilinear_matches_interpolate(size_in, size_out):
+    g = torch.Generator().manual_seed(size_in[0])
+    x = _bf(torch.randn(2, 64, *size_in, generator=g)).to(DEV)
+    want = F.interpolate(x, size_out, mode='bilinear', align_corners=True)
+    img = conv3d_ops.pack_image(x)
+    out = conv3d_ops.resize_bilinear(img, size_out)
+    got = conv3d_ops.unpack_image(out)
+    # fp32 blends of the same four bf16 taps, one bf16 rounding at the end
+    assert float((got - _bf(want)).abs().max()) <= 2.0 ** -6 * float(want.abs().max())
+    grid = out.rows.view(2, size_out[0] + 2, size_out[1] + 2, 64).float().clone()
+    grid[:, 1:-1, 1:-1] = 0
+    assert float(grid.abs().sum()) == 0.0

@@ -122,3 +122,38 @@ def test_encoder_is_graph_capturable():
     with torch.no_grad():
         want2 = enc.forward_features(x * 0.5)['x_prenorm']
     assert torch.equal(got2, want2)
+
+
+@pytest.mark.gpu
+def test_dpt_head_bf16_mfma_convs_match_autocast():
+    """head_dtype = bf16: the ResidualConvUnits and output convs run on the 2-D
+    implicit-GEMM kernel; same result as PyTorch's bf16 autocast of the same
+    head within bf16 noise, and the native conv really ran."""
+    import torch
+    from veon_amd import _lib
+    from veon_amd.models import build_neck
+    from veon_amd.models.depth_anything import dpt
+    torch.manual_seed(0)
+    m = build_neck(dict(type='DepthAnythingV2Adaptor', max_depth=80.0, use_lora=True,
+                        lora_r=4, encoder='vits', features=128,
+                        out_channels=[48, 96, 192, 384])).to('cuda:0').eval()
+    x = torch.randn(2, 3, 56, 84, device='cuda:0')
+    m.head_dtype = torch.bfloat16
+    with torch.no_grad():
+        feats = m.encode(x)
+        before = _lib.CALLS.get('veon_conv2d_k3_bf16', 0)
+        got = m.decode(feats, 4, 6)
+        ran = _lib.CALLS.get('veon_conv2d_k3_bf16', 0) - before
+        ok = dpt._hip_convs_ok
+        dpt._hip_convs_ok = lambda *a, **k: False          # PyTorch autocast path
+        try:
+            want = m.decode(feats, 4, 6)
+        finally:
+            dpt._hip_convs_ok = ok
+        m.head_dtype = None
+        ref32 = m.decode(feats, 4, 6)
+    assert ran == 2 + 3 * 4 + 2, ran   # refinenet4: 2 convs; 3 blocks x 4; 2 output convs
+    assert got.shape == want.shape == (2, 1, 56, 84)
+    err_hip = ((got - ref32).norm() / ref32.norm()).item()
+    err_amp = ((want - ref32).norm() / ref32.norm()).item()
+    assert err_hip < max(2.0 * err_amp, 2e-2), (err_hip, err_amp)

@@ -3,7 +3,8 @@
 (BASELINE config 3 shape: VEON-B, bf16, 6 cameras 256x704, synthetic inputs,
 random weights):
 
-  DepthAnythingV2 (MFMA encoder, hipGraph | DPT head on PyTorch/MIOpen)
+  DepthAnythingV2 (MFMA encoder, hipGraph | DPT head: 3x3 convs on the MFMA conv
+    kernel in a padded bf16 pipeline, the rest PyTorch)
     -> metric depth -> fused block-min + two-hot depth
   CLIP ViT-B/16 trunk (MFMA) -> stand-in 1x1 projection to C=256 at Hf x Wf
   -> sync-free lift with the fused 2x2x2 max-pool, written straight into
@@ -152,7 +153,7 @@ def run(enc='vitb', head_bf16=True, graph_clip=False, dev='cuda:0', iters=20,
         t_e = timeit(lambda: g_enc(x252), iters)
         t_d = timeit(lambda: depth_branch(img), iters)
         say('depth branch %.2f ms (encoder graph %.2f ms, DPT head %s)' % (
-            t_d, t_e, 'bf16 autocast' if head_bf16 else 'fp32'))
+            t_d, t_e, 'bf16, 3x3 convs on the MFMA conv kernel' if head_bf16 else 'fp32 PyTorch/MIOpen'))
         t_s = timeit(lambda: sem_branch(img), iters)
         say('semantic trunk %.2f ms (%s)' % (t_s, 'hipGraph' if graph_clip else 'eager'))
         t_l = timeit(lambda: vt([f] + geom, d), iters)

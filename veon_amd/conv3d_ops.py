@@ -178,3 +178,19 @@ def conv2d_k3(img, w_packed, scale=None, shift=None, resid=None, relu=False,
             B, Y, X, Cin, Cout, 1 if relu else 0, _lib.stream_ptr(dev))
     _lib.check(st, 'veon_conv2d_k3_bf16')
     return out
+
+
+def resize_bilinear(img, size, out=None):
+    """F.interpolate(mode='bilinear', align_corners=True) on a PaddedImage."""
+    dev = _lib.require_device(img.storage)
+    B, C, Yi, Xi = img.shape
+    Yo, Xo = int(size[0]), int(size[1])
+    if out is None:
+        out = PaddedImage(B, C, Yo, Xo, dev)
+    assert out.shape == (B, C, Yo, Xo)
+    with torch.cuda.device(dev):
+        st = _lib.lib().veon_image_resize_bilinear(
+            _lib.ptr(img.rows), _lib.ptr(out.rows), B, C, Yi, Xi, Yo, Xo,
+            _lib.stream_ptr(dev))
+    _lib.check(st, 'veon_image_resize_bilinear')
+    return out

@@ -277,6 +277,49 @@ __global__ __launch_bounds__(256) void k_volume_unpack(
   }
 }
 
+// Bilinear resize (align_corners = True, F.interpolate semantics) between two
+// padded channels-last bf16 images; writes the interior only, so the zero halo
+// of the destination survives.  One lane = 8 channels (16 B) of one output
+// pixel; coordinates and blends in fp32 as PyTorch does for bf16 inputs.
+__global__ __launch_bounds__(256) void k_resize_bilinear_padded(
+    const bf16_t* __restrict__ in, bf16_t* __restrict__ out, int B, int C, int Yi,
+    int Xi, int Yo, int Xo, float sy, float sx) {
+  const int c8 = C / 8;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t total = (int64_t)B * Yo * Xo * c8;
+  if (idx >= total) return;
+  const int cc = (int)(idx % c8) * 8;
+  int64_t p = idx / c8;
+  const int xo = (int)(p % Xo);
+  p /= Xo;
+  const int yo = (int)(p % Yo);
+  const int b = (int)(p / Yo);
+  const float fy = sy * yo, fx = sx * xo;
+  const int y0 = (int)fy, x0 = (int)fx;
+  const int y1 = y0 + (y0 < Yi - 1), x1 = x0 + (x0 < Xi - 1);
+  const float ly = fy - y0, lx = fx - x0, hy = 1.f - ly, hx = 1.f - lx;
+  const int Xip = Xi + 2, Xop = Xo + 2;
+  const bf16_t* ib = in + ((int64_t)b * (Yi + 2) * Xip) * C + cc;
+  auto px = [&](int y, int x) {
+    return *reinterpret_cast<const bf16x8*>(ib + ((int64_t)(y + 1) * Xip + x + 1) * C);
+  };
+  const bf16x8 a = px(y0, x0), bq = px(y0, x1), c = px(y1, x0), d = px(y1, x1);
+  unsigned o[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    float v[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int e = 2 * k + h;
+      v[h] = hy * (hx * bf2f((bf16_t)a[e]) + lx * bf2f((bf16_t)bq[e])) +
+             ly * (hx * bf2f((bf16_t)c[e]) + lx * bf2f((bf16_t)d[e]));
+    }
+    o[k] = pack_bf16(v[0], v[1]);
+  }
+  bf16_t* op = out + (((int64_t)b * (Yo + 2) + yo + 1) * Xop + xo + 1) * C + cc;
+  *reinterpret_cast<uint4*>(op) = make_uint4(o[0], o[1], o[2], o[3]);
+}
+
 }  // namespace
 
 extern "C" {
@@ -435,6 +478,24 @@ int veon_image_pack_bf16(const void* nchw, int nchw_is_bf16, void* padded, int B
 int veon_image_unpack(const void* padded, void* nchw, int nchw_is_bf16, int B,
                       int C, int Y, int X, void* stream) {
   return pack_impl(true, 0, nchw_is_bf16, nchw, padded, B, C, 1, Y, X, stream);
+}
+
+int veon_image_resize_bilinear(const void* in_padded, void* out_padded, int B,
+                               int C, int Yi, int Xi, int Yo, int Xo,
+                               void* stream) {
+  if (B <= 0 || C <= 0 || C % 8 != 0 || Yi <= 0 || Xi <= 0 || Yo <= 0 || Xo <= 0 ||
+      !in_padded || !out_padded || !al16(in_padded) || !al16(out_padded))
+    return VEON_ERR_BAD_ARG;
+  const int64_t total = (int64_t)B * Yo * Xo * (C / 8);
+  const int64_t blocks = (total + 255) / 256;
+  if (blocks > 0x7fffffffLL) return VEON_ERR_BAD_ARG;
+  const float sy = Yo > 1 ? (float)(Yi - 1) / (float)(Yo - 1) : 0.f;
+  const float sx = Xo > 1 ? (float)(Xi - 1) / (float)(Xo - 1) : 0.f;
+  hipLaunchKernelGGL(k_resize_bilinear_padded, dim3((unsigned)blocks), dim3(256), 0,
+                     static_cast<hipStream_t>(stream),
+                     static_cast<const bf16_t*>(in_padded),
+                     static_cast<bf16_t*>(out_padded), B, C, Yi, Xi, Yo, Xo, sy, sx);
+  return launch_status();
 }
 
 }  // extern "C"

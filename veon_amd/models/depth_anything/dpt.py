@@ -1,14 +1,57 @@
 """DepthAnythingV2 depth estimator -- mirror of
 mmdet3d/models/depth_anything/dpt.py (DPTHead :39-150, DepthAnythingV2Adaptor
 :226-263) and util/blocks.py.  The encoder's dense contractions run on MFMA
-(``dinov2.py``); the DPT convolution head stays plain PyTorch / MIOpen
-(SURVEY 2 #6).  Same module / parameter names as the reference."""
+(``dinov2.py``).  The DPT convolution head is plain PyTorch / MIOpen in fp32
+(the reference's numerics); when the adaptor runs the head in bf16
+(``head_dtype = torch.bfloat16``) its heavy 3x3 convolutions -- the
+ResidualConvUnits of the fusion blocks and the two output convolutions -- go to
+the implicit-GEMM MFMA kernel (csrc/conv3d.hip, 2-D mode) with bias / ReLU /
+identity fused, the rest (1x1 convs, transposed convs, bilinear resizes) stays
+PyTorch.  Same module / parameter names as the reference."""
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ... import conv3d_ops, vit_ops
 from ..builder import register_neck
 from .dinov2 import DINOv2Adaptor
+
+
+def _hip_convs_ok(x, *convs):
+    """bf16 inference on a ROCm device with MFMA-shaped channel counts."""
+    return (x.is_cuda and x.dtype == torch.bfloat16 and not torch.is_grad_enabled()
+            and all(c.in_channels % 64 == 0 and c.kernel_size == (3, 3)
+                    and c.stride == (1, 1) and c.padding == (1, 1) for c in convs))
+
+
+class _HipConv:
+    """Packed bf16 weight + fp32 bias of one nn.Conv2d, and per-shape buffers."""
+
+    def __init__(self, conv):
+        self.w = conv3d_ops.pack_weight2d(conv.weight)
+        self.cout = conv.out_channels
+        self.shift = torch.zeros(self.w.shape[0], device=conv.weight.device)
+        if conv.bias is not None:
+            self.shift[:self.cout] = conv.bias.detach().float()
+        self.bufs = {}
+
+    def out_buf(self, img, tag=0):
+        key = (img.shape[0], img.shape[2], img.shape[3], tag)
+        if key not in self.bufs:
+            self.bufs[key] = conv3d_ops.PaddedImage(img.shape[0], self.w.shape[0],
+                                                    img.shape[2], img.shape[3], img.device)
+        return self.bufs[key]
+
+    def __call__(self, img, relu=False, resid=None, tag=0):
+        return conv3d_ops.conv2d_k3(img, self.w, None, self.shift, resid=resid,
+                                    relu=relu, out=self.out_buf(img, tag))
+
+
+def _hip_cache(mod, name, conv):
+    cache = mod.__dict__.setdefault('_hip_convs', {})
+    if name not in cache:
+        cache[name] = _HipConv(conv)
+    return cache[name]
 
 
 class ResidualConvUnit(nn.Module):
@@ -30,6 +73,18 @@ class ResidualConvUnit(nn.Module):
             out = self.bn2(out)
         return out + x
 
+    def train(self, mode=True):
+        self.__dict__.pop('_hip_convs', None)
+        return super().train(mode)
+
+    def hip_forward(self, img, scratch):
+        """conv2(relu(conv1(relu(x)))) + x on a PaddedImage: ReLU of the input
+        is one elementwise pass (the zero halo stays zero), bias + ReLU and
+        bias + identity are the convs' epilogues."""
+        torch.clamp_min(img.rows, 0, out=scratch.rows)
+        u = _hip_cache(self, 'conv1', self.conv1)(scratch, relu=True, tag=1)
+        return _hip_cache(self, 'conv2', self.conv2)(u, resid=img, tag=2)
+
 
 class FeatureFusionBlock(nn.Module):
     """util/blocks.py:86-148 (expand=False, align_corners=True)."""
@@ -40,6 +95,50 @@ class FeatureFusionBlock(nn.Module):
         self.resConfUnit1 = ResidualConvUnit(features, bn)
         self.resConfUnit2 = ResidualConvUnit(features, bn)
         self.size = size
+
+    def _buf(self, tag, B, C, H, W, device):
+        bufs = self.__dict__.setdefault('_hip_bufs', {})
+        key = (tag, B, C, H, W)
+        if key not in bufs:
+            bufs[key] = conv3d_ops.PaddedImage(B, C, H, W, device)
+        return bufs[key]
+
+    def train(self, mode=True):
+        self.__dict__.pop('_hip_bufs', None)
+        self.__dict__.pop('_hip_1x1', None)
+        return super().train(mode)
+
+    def hip_ok(self, x):
+        u1, u2 = self.resConfUnit1, self.resConfUnit2
+        return (not u1.bn and _hip_convs_ok(x, u1.conv1, u1.conv2, u2.conv1, u2.conv2)
+                and self.out_conv.in_channels % 64 == 0
+                and self.out_conv.out_channels % 8 == 0)
+
+    def hip_block(self, x0, x1, size):
+        """The whole block on PaddedImages: [x0 += RCU1(x1)], RCU2, 1x1 out_conv
+        as a GEMM on the rows, bilinear resize.  The 1x1 conv is applied BEFORE
+        the resize: a per-pixel affine map and a per-channel interpolation with
+        weights summing to one commute, and it is 4x less work there.  (x0 is
+        updated in place; its producer does not need it afterwards.)"""
+        B, C, H, W = x0.shape
+        scratch = self._buf('relu', B, C, H, W, x0.device)
+        if x1 is not None:
+            r = self.resConfUnit1.hip_forward(x1, scratch)
+            x0.rows.add_(r.rows)
+        y = self.resConfUnit2.hip_forward(x0, scratch)
+        if '_hip_1x1' not in self.__dict__:
+            oc = self.out_conv
+            self.__dict__['_hip_1x1'] = (
+                oc.weight.detach().float().view(oc.out_channels, -1)
+                .to(torch.bfloat16).contiguous(),
+                oc.bias.detach().float().contiguous())
+        w, bias = self.__dict__['_hip_1x1']
+        z = self._buf('1x1', B, w.shape[0], H, W, x0.device)
+        vit_ops.linear(y.rows, w, bias, vit_ops.EPI_BF16, out=z.rows)
+        if size is None:
+            size = self.size if self.size is not None else (2 * H, 2 * W)
+        out = self._buf('up', B, w.shape[0], int(size[0]), int(size[1]), x0.device)
+        return conv3d_ops.resize_bilinear(z, size, out=out)
 
     def forward(self, *xs, size=None):
         out = xs[0]
@@ -102,6 +201,11 @@ class DPTHead(nn.Module):
         l1, l2, l3, l4 = out
         s = self.scratch
         l1, l2, l3, l4 = s.layer1_rn(l1), s.layer2_rn(l2), s.layer3_rn(l3), s.layer4_rn(l4)
+        oc2 = s.output_conv2
+        if (all(getattr(s, 'refinenet%d' % i).hip_ok(l1) for i in (1, 2, 3, 4))
+                and _hip_convs_ok(l1, s.output_conv1, oc2[0])
+                and all(t.dtype == torch.bfloat16 for t in (l2, l3, l4))):
+            return self._hip_refine(l1, l2, l3, l4, patch_h, patch_w)
         p4 = s.refinenet4(l4, size=l3.shape[2:])
         p3 = s.refinenet3(p4, l3, size=l2.shape[2:])
         p2 = s.refinenet2(p3, l2, size=l1.shape[2:])
@@ -110,6 +214,41 @@ class DPTHead(nn.Module):
         out = F.interpolate(out, (int(patch_h * 14), int(patch_w * 14)),
                             mode='bilinear', align_corners=True)
         return s.output_conv2(out)
+
+    def train(self, mode=True):
+        self.__dict__.pop('_hip_convs', None)
+        self.__dict__.pop('_hip_in', None)
+        return super().train(mode)
+
+    def _hip_refine(self, l1, l2, l3, l4, patch_h, patch_w):
+        """Fusion blocks + output convs entirely in the padded channels-last
+        bf16 layout of the MFMA conv kernel: four packs in, one unpack out."""
+        s = self.scratch
+        ins = self.__dict__.setdefault('_hip_in', {})
+
+        def packed(tag, t):
+            key = (tag,) + tuple(t.shape)
+            if key not in ins:
+                ins[key] = conv3d_ops.PaddedImage(*t.shape, t.device)
+            return conv3d_ops.pack_image(t, out=ins[key])
+        i1, i2, i3, i4 = (packed(k, t) for k, t in enumerate((l1, l2, l3, l4)))
+        p4 = s.refinenet4.hip_block(i4, None, l3.shape[2:])
+        p3 = s.refinenet3.hip_block(p4, i3, l2.shape[2:])
+        p2 = s.refinenet2.hip_block(p3, i2, l1.shape[2:])
+        p1 = s.refinenet1.hip_block(p2, i1, None)
+        o = _hip_cache(self, 'output_conv1', s.output_conv1)(p1)
+        size = (int(patch_h * 14), int(patch_w * 14))
+        key = ('final',) + (o.shape[0], o.shape[1]) + size
+        if key not in ins:
+            ins[key] = conv3d_ops.PaddedImage(o.shape[0], o.shape[1], size[0], size[1],
+                                              o.device)
+        o = conv3d_ops.resize_bilinear(o, size, out=ins[key])
+        oc2 = s.output_conv2
+        o = _hip_cache(self, 'output_conv2', oc2[0])(o, relu=True)  # conv + ReLU
+        out = conv3d_ops.unpack_image(o, torch.bfloat16, channels=oc2[0].out_channels)
+        for layer in list(oc2)[2:]:
+            out = layer(out)
+        return out
 
 
 _TAPS = {'vits': [2, 5, 8, 11], 'vitb': [2, 5, 8, 11], 'vitl': [4, 11, 17, 23]}
