@@ -369,6 +369,10 @@ int veon_image_unpack(const void *padded, void *nchw, int nchw_is_bf16, int B,
 int veon_image_resize_bilinear(const void *in_padded, void *out_padded, int B,
                                int C, int Yi, int Xi, int Yo, int Xo,
                                void *stream);
+/* out (B,Y,X) fp32 = act(1x1 conv C -> 1 of a padded image + bias); C in {32, 64};
+ * act 0 none / 1 ReLU / 2 sigmoid (the tail of DPTHead.output_conv2, dpt.py). */
+int veon_image_dot(const void *in_padded, const float *w, float bias, float *out,
+                   int B, int C, int Y, int X, int act, void *stream);
 /* (B,C,Z,Y,X) fp32 <-> interior of the padded channels-last bf16 grid (the halo
  * is not touched: allocate the grid zeroed once). */
 int veon_volume_pack_bf16(const float *ncdhw, void *padded, int B, int C, int Z,

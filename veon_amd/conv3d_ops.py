@@ -120,11 +120,16 @@ def pack_image(x, out=None):
     dev = _lib.require_device(x)
     if x.dtype not in (torch.float32, torch.bfloat16):
         x = x.float()
-    x = x.contiguous()
     B, C, Y, X = x.shape
     if out is None:
         out = PaddedImage(B, C, Y, X, dev)
     assert out.shape == tuple(x.shape)
+    if not x.is_contiguous() and x.is_contiguous(memory_format=torch.channels_last):
+        # already channels-last (e.g. a MIOpen NHWC result): one strided copy
+        # into the interior, no transpose
+        out.rows.view(B, Y + 2, X + 2, C)[:, 1:-1, 1:-1].copy_(x.permute(0, 2, 3, 1))
+        return out
+    x = x.contiguous()
     with torch.cuda.device(dev):
         st = _lib.lib().veon_image_pack_bf16(
             _lib.ptr(x), 1 if x.dtype == torch.bfloat16 else 0, _lib.ptr(out.rows),
@@ -193,4 +198,19 @@ def resize_bilinear(img, size, out=None):
             _lib.ptr(img.rows), _lib.ptr(out.rows), B, C, Yi, Xi, Yo, Xo,
             _lib.stream_ptr(dev))
     _lib.check(st, 'veon_image_resize_bilinear')
+    return out
+
+
+def image_dot(img, w, bias, act='none'):
+    """1x1 conv C -> 1 (+activation) of a PaddedImage -> (B,1,H,W) fp32.
+    w fp32 [C], act in none / relu / sigmoid."""
+    dev = _lib.require_device(img.storage, w)
+    B, C, Y, X = img.shape
+    assert w.dtype == torch.float32 and w.numel() >= C and w.is_contiguous()
+    out = torch.empty((B, 1, Y, X), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        st = _lib.lib().veon_image_dot(
+            _lib.ptr(img.rows), _lib.ptr(w), float(bias), _lib.ptr(out), B, C, Y, X,
+            {'none': 0, 'relu': 1, 'sigmoid': 2}[act], _lib.stream_ptr(dev))
+    _lib.check(st, 'veon_image_dot')
     return out

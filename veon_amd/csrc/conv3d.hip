@@ -320,6 +320,32 @@ __global__ __launch_bounds__(256) void k_resize_bilinear_padded(
   *reinterpret_cast<uint4*>(op) = make_uint4(o[0], o[1], o[2], o[3]);
 }
 
+// out[b][y][x] = act(sum_c in[b][y][x][c] * w[c] + bias): the last 1x1 conv of a
+// dense-prediction head (C -> 1) with its activation, straight from the padded
+// channels-last image to a planar fp32 map.  One lane per pixel; a wave reads a
+// contiguous run of rows.  act: 0 none, 1 ReLU, 2 sigmoid.
+template <int C>
+__global__ __launch_bounds__(256) void k_image_dot(
+    const bf16_t* __restrict__ in, const float* __restrict__ w, float bias,
+    float* __restrict__ out, int B, int Y, int X, int act) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (int64_t)B * Y * X) return;
+  const int x = (int)(idx % X);
+  const int y = (int)((idx / X) % Y);
+  const int b = (int)(idx / ((int64_t)X * Y));
+  const bf16_t* p = in + (((int64_t)b * (Y + 2) + y + 1) * (X + 2) + x + 1) * C;
+  float acc = bias;
+#pragma unroll
+  for (int c = 0; c < C; c += 8) {
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(p + c);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc = fmaf(bf2f((bf16_t)v[k]), w[c + k], acc);
+  }
+  if (act == 1) acc = fmaxf(acc, 0.f);
+  if (act == 2) acc = 1.f / (1.f + __expf(-acc));
+  out[idx] = acc;
+}
+
 }  // namespace
 
 extern "C" {
@@ -495,6 +521,27 @@ int veon_image_resize_bilinear(const void* in_padded, void* out_padded, int B,
                      static_cast<hipStream_t>(stream),
                      static_cast<const bf16_t*>(in_padded),
                      static_cast<bf16_t*>(out_padded), B, C, Yi, Xi, Yo, Xo, sy, sx);
+  return launch_status();
+}
+
+int veon_image_dot(const void* in_padded, const float* w, float bias, float* out,
+                   int B, int C, int Y, int X, int act, void* stream) {
+  if (B <= 0 || Y <= 0 || X <= 0 || !in_padded || !w || !out || !al16(in_padded) ||
+      act < 0 || act > 2)
+    return VEON_ERR_BAD_ARG;
+  const int64_t total = (int64_t)B * Y * X;
+  const int64_t blocks = (total + 255) / 256;
+  if (blocks > 0x7fffffffLL) return VEON_ERR_BAD_ARG;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const bf16_t* I = static_cast<const bf16_t*>(in_padded);
+  if (C == 32)
+    hipLaunchKernelGGL(k_image_dot<32>, dim3((unsigned)blocks), dim3(256), 0, s, I, w,
+                       bias, out, B, Y, X, act);
+  else if (C == 64)
+    hipLaunchKernelGGL(k_image_dot<64>, dim3((unsigned)blocks), dim3(256), 0, s, I, w,
+                       bias, out, B, Y, X, act);
+  else
+    return VEON_ERR_BAD_ARG;
   return launch_status();
 }
 

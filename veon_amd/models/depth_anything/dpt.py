@@ -218,6 +218,7 @@ class DPTHead(nn.Module):
     def train(self, mode=True):
         self.__dict__.pop('_hip_convs', None)
         self.__dict__.pop('_hip_in', None)
+        self.__dict__.pop('_hip_tail', None)
         return super().train(mode)
 
     def _hip_refine(self, l1, l2, l3, l4, patch_h, patch_w):
@@ -245,8 +246,24 @@ class DPTHead(nn.Module):
         o = conv3d_ops.resize_bilinear(o, size, out=ins[key])
         oc2 = s.output_conv2
         o = _hip_cache(self, 'output_conv2', oc2[0])(o, relu=True)  # conv + ReLU
+        tail = list(oc2)[2:]
+        last = tail[0] if tail else None
+        if (isinstance(last, nn.Conv2d) and last.out_channels == 1
+                and last.kernel_size == (1, 1) and o.shape[1] in (32, 64)
+                and len(tail) <= 2
+                and (len(tail) == 1 or isinstance(tail[1], (nn.Sigmoid, nn.ReLU)))):
+            # 1x1 conv to one channel + its activation straight off the padded rows
+            if '_hip_tail' not in self.__dict__:
+                self.__dict__['_hip_tail'] = (
+                    last.weight.detach().float().reshape(-1).contiguous(),
+                    float(last.bias.detach().float().item()) if last.bias is not None
+                    else 0.0)
+            w, b = self.__dict__['_hip_tail']
+            act = 'none' if len(tail) == 1 else \
+                ('sigmoid' if isinstance(tail[1], nn.Sigmoid) else 'relu')
+            return conv3d_ops.image_dot(o, w, b, act)
         out = conv3d_ops.unpack_image(o, torch.bfloat16, channels=oc2[0].out_channels)
-        for layer in list(oc2)[2:]:
+        for layer in tail:
             out = layer(out)
         return out
 
