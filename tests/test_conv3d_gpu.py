@@ -5,7 +5,6 @@ Tolerance: operands are bf16 on both sides and accumulation is fp32, so the only
 differences are the fp32 summation order and the final bf16 rounding of the
 kernel's output: |got - want| <= 2^-7 * |want| + 2e-3 * rms(want) per element.
 """
-import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F

@@ -4,7 +4,6 @@ partition, the all-reduce and the max-pool-after-reduce order."""
 import os
 import socket
 
-import numpy as np
 import pytest
 import torch
 import torch.distributed as dist

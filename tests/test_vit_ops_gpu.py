@@ -2,7 +2,6 @@
 same ops on the same (bf16-rounded) operands.  Tolerances are stated per test:
 the products are exact in fp32 accumulation, so the error budget is the bf16
 rounding of the OUTPUT (2^-9 relative) plus accumulation-order noise."""
-import numpy as np
 import pytest
 import torch
 

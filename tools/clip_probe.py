@@ -3,7 +3,6 @@
 import os
 import sys
 import torch
-import torch.nn.functional as F
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from veon_amd import vit_ops  # noqa: E402
 from veon_amd.models.semantic_net import ClipVisualTrunk  # noqa: E402

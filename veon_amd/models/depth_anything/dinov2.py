@@ -16,7 +16,6 @@ Two execution paths share the parameters:
   which is the reference's own formulation (attention.py:56-69, block.py:85-110).
 """
 import math
-from functools import partial
 
 import torch
 import torch.nn as nn
