@@ -146,6 +146,25 @@ def run(enc='vitb', head_bf16=True, graph_clip=False, dev='cuda:0', iters=20,
         def whole_serial(im):
             return lift_body(sem_branch(im), depth_branch(im))
 
+        tail = torch.cuda.Stream()
+
+        def whole_pipelined(im):
+            # as `whole`, with lift + body + heads on a third stream so that the
+            # next sample's encoders need not wait for this sample's body (the
+            # stage buffers are private to their stage; throughput loop only)
+            cur = torch.cuda.current_stream()
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                ft = sem_branch(im)
+            dp = depth_branch(im)
+            tail.wait_stream(cur)
+            tail.wait_stream(side)
+            with torch.cuda.stream(tail):
+                out = lift_body(ft, dp)
+            ft.record_stream(tail)
+            dp.record_stream(tail)
+            return out
+
         out = whole(img)
         torch.cuda.synchronize()
         say('depth', tuple(d.shape), 'feat', tuple(f.shape), 'out',
@@ -166,6 +185,8 @@ def run(enc='vitb', head_bf16=True, graph_clip=False, dev='cuda:0', iters=20,
         say('chained, one stream %.2f ms' % t_ws)
         t_w = timeit(lambda: whole(img), iters)
         say('chained, encoder branches on two streams %.2f ms' % t_w)
+        t_p = timeit(lambda: whole_pipelined(img), iters)
+        say('chained, + tail of sample i under the encoders of i+1 %.2f ms' % t_p)
     say('%s: depth %.2f | semantic %.2f | lift %.3f | lift+body+heads %.3f | chained %.2f ms '
         '-> %.1f 6-cam samples/s' % (enc, t_d, t_s, t_l, t_lb, t_w, 1e3 / t_w))
     return dict(encoder_ms=t_e, depth_branch_ms=t_d, semantic_ms=t_s, lift_ms=t_l,
