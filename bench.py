@@ -131,8 +131,8 @@ def bench_hotpath(args, rank, world, dev, dist):
         'config': {'workload': 'VEONB: 6-cam 256x704 -> DA-V2 ViT-B (MFMA encoder, DPT head '
                                'bf16 with its 3x3 convs on the MFMA conv kernel) + CLIP ViT-B/16 trunk (MFMA) + sync-free '
                                'lift (D=88, C=256, 200x200x16, fused 2x2x2 max-pool) + 4x '
-                               'ResBlock3D body + occ/sem heads (MFMA); random weights; SAN side '
-                               'adapter / HSA / upsample / classifier not included',
+                               'ResBlock3D body + occ/sem heads + open-vocab classifier (MFMA) + upsampled '
+                               'outputs; random weights; SAN side adapter / HSA not included',
                    'parallelism': 'replicas x%d' % world,
                    'stages_ms': {k: round(v, 3) for k, v in r.items() if k.endswith('_ms')}},
         'roofline': {'kernel': 'k_conv3d_k3 (8 launches, AlignNetOcc3D body)', 'bound': 'mfma',

@@ -270,3 +270,26 @@ def test_resize_bilinear_matches_interpolate(size_in, size_out):
     grid = out.rows.view(2, size_out[0] + 2, size_out[1] + 2, 64).float().clone()
     grid[:, 1:-1, 1:-1] = 0
     assert float(grid.abs().sum()) == 0.0
+
+
+def test_fused_semantic_inference_on_padded_volume():
+    """PredHead3DSem(return_volume) -> classifier GEMM on the padded rows -> upsample
+    of the class logits, vs the reference order on the head's fp32 output."""
+    from veon_amd.models.semantic_net import (PredHead3DSem, semantic_inference_3d,
+                                              semantic_inference_3d_fused)
+    torch.manual_seed(2)
+    sem = PredHead3DSem(64, 128).to(DEV).eval()
+    for m in sem.modules():
+        if isinstance(m, torch.nn.Conv3d):
+            m.weight.data = _bf(m.weight.data)
+    W = (torch.randn(17, 128, device=DEV) * 2)
+    x = _bf(torch.randn(1, 64, 4, 9, 11)).to(DEV)
+    with torch.no_grad():
+        vol = sem(conv3d_ops.pack(x), return_volume=True)
+        assert isinstance(vol, conv3d_ops.PaddedVolume)
+        got = semantic_inference_3d_fused(W, vol, (8, 18, 22))
+        feat = sem(x)                                  # (1,128,4,9,11) fp32
+        want = semantic_inference_3d(W, feat, (8, 18, 22))
+    assert got.shape == want.shape == (1, 17, 8, 18, 22)
+    rel = ((got - want).norm() / want.norm()).item()
+    assert rel < 1.5e-2, rel

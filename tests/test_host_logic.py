@@ -228,3 +228,18 @@ def test_align_body_and_heads_reproduce_reference_vectors():
         assert torch.allclose(y, torch.from_numpy(g['block_out']), atol=1e-5)
         assert torch.allclose(occ(y), torch.from_numpy(g['occ_out']), atol=1e-5)
         assert torch.allclose(sem(y), torch.from_numpy(g['sem_out']), atol=1e-5)
+
+
+def test_fused_semantic_inference_equals_reference_order():
+    """Classify-then-upsample == upsample-then-classify (both maps are linear,
+    interpolation weights sum to one): san_in_veon_temporal.py:196-201, 257-259."""
+    import torch
+    from veon_amd.models.semantic_net import (semantic_inference_3d,
+                                              semantic_inference_3d_fused)
+    torch.manual_seed(0)
+    W = torch.randn(17, 64) * 3
+    feat = torch.rand(2, 64, 3, 5, 6) - 0.5
+    a = semantic_inference_3d(W, feat, (6, 10, 12))
+    b = semantic_inference_3d_fused(W, feat, (6, 10, 12))
+    assert a.shape == b.shape == (2, 17, 6, 10, 12)
+    assert torch.allclose(a, b, atol=2e-5, rtol=1e-5)

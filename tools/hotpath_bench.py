@@ -10,9 +10,10 @@ random weights):
   -> sync-free lift with the fused 2x2x2 max-pool, written straight into
   -> the AlignNetOcc3D Conv3d body's padded bf16 input, 4 ResBlock3D on MFMA
   -> PredHead3DOcc / PredHead3DSem (1x1x1 convs as GEMMs on the padded rows)
+  -> open-vocabulary classifier (17 x 768) at the head's resolution + trilinear
+     upsample of the 17 + 2 output channels to 16 x 200 x 200
 
-The SAN side adapter, HSA network, trilinear upsampling and the classifier einsum
-are NOT part of this (PyTorch in the reference, not rebuilt), so this is the
+The SAN side adapter and the HSA network are NOT part of this (PyTorch in the reference, not rebuilt), so this is the
 throughput of the rows SURVEY section 8 puts on the hot path plus row f1, not a
 full VEON end-to-end number.
 
@@ -30,7 +31,8 @@ from veon_amd import conv3d_ops, synthetic  # noqa: E402
 from veon_amd.graphs import GraphedCallable  # noqa: E402
 from veon_amd.models import build_neck  # noqa: E402
 from veon_amd.models.semantic_net import (AlignBody3D, ClipVisualTrunk,  # noqa: E402
-                                          PredHead3DOcc, PredHead3DSem)
+                                          PredHead3DOcc, PredHead3DSem,
+                                          semantic_inference_3d_fused)
 
 
 def timeit(fn, iters=20):
@@ -74,6 +76,7 @@ def run(enc='vitb', head_bf16=True, graph_clip=False, dev='cuda:0', iters=20,
     occ_head = PredHead3DOcc(256, 2).to(dev).eval()
     sem_head = PredHead3DSem(256, 768).to(dev).eval()
     lifted = conv3d_ops.PaddedVolume(1, 256, 8, 100, 100, dev)
+    ov_classifier = torch.randn(17, 768, device=dev)  # 17 Occ3D classes x CLIP dim
     rig = synthetic.make_rig(1, 6, size)
     geom = [t.to(dev) for t in synthetic.rig_inputs(rig)]
     img = torch.randn(6, 3, *size, device=dev)
@@ -119,7 +122,13 @@ def run(enc='vitb', head_bf16=True, graph_clip=False, dev='cuda:0', iters=20,
             # the fused max-pool kernel writes the body's padded bf16 input; the
             # heads read the body's padded output: no pack / unpack in between
             x = body(vt([feat] + geom, depth, out_volume=lifted), return_volume=True)
-            return occ_head(x), sem_head(x)
+            bin_occ = F.interpolate(occ_head(x), size=(16, 200, 200), mode='trilinear',
+                                    align_corners=False)
+            # class logits at the head's resolution, then upsample 17 channels
+            # (the reference upsamples 768 and classifies at 16 x 200 x 200)
+            sem_occ = semantic_inference_3d_fused(
+                ov_classifier, sem_head(x, return_volume=True), (16, 200, 200))
+            return bin_occ, sem_occ
 
         # NOTE: lift and body run eagerly here.  Each replays fine from its own
         # hipGraph (tests, bench.py, tools/time_forward.py), but in this script a
@@ -180,7 +189,7 @@ def run(enc='vitb', head_bf16=True, graph_clip=False, dev='cuda:0', iters=20,
         t_b = timeit(lambda: body(lifted, return_volume=True), iters)
         say('Conv3d body %.3f ms' % t_b)
         t_lb = timeit(lambda: lift_body(f, d), iters)
-        say('lift + Conv3d body + occ/sem heads %.3f ms' % t_lb)
+        say('lift + Conv3d body + heads + open-vocab classifier + upsample %.3f ms' % t_lb)
         t_ws = timeit(lambda: whole_serial(img), iters)
         say('chained, one stream %.2f ms' % t_ws)
         t_w = timeit(lambda: whole(img), iters)

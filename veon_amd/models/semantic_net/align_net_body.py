@@ -110,7 +110,7 @@ class _PredHead3D(nn.Module):
             return True
         return x.is_cuda and not self.training and not torch.is_grad_enabled()
 
-    def _run(self, x):
+    def _run(self, x, return_volume=False):
         if not self._hip_ok(x):
             if isinstance(x, conv3d_ops.PaddedVolume):
                 x = conv3d_ops.unpack(x)
@@ -120,6 +120,8 @@ class _PredHead3D(nn.Module):
         vol = x if isinstance(x, conv3d_ops.PaddedVolume) else conv3d_ops.pack(x)
         for cm in self._chain():
             vol = _pointwise(vol, cm)
+        if return_volume:
+            return vol
         out = conv3d_ops.unpack(vol)
         return out[:, :self._chain()[-1].conv.out_channels]
 
@@ -159,8 +161,53 @@ class PredHead3DSem(_PredHead3D):
                                       bias=False, norm=False, act=False)
         self.use_checkpoint = use_checkpoint
 
-    def forward(self, x):
-        return self._run(x).sigmoid() - 0.5
+    def forward(self, x, return_volume=False):
+        """``return_volume`` (MFMA path only): keep the result -- sigmoid - 0.5
+        applied in place on the bf16 rows -- as the PaddedVolume that
+        ``semantic_inference_3d_fused`` consumes."""
+        out = self._run(x, return_volume)
+        if isinstance(out, conv3d_ops.PaddedVolume):
+            # sigmoid(x) - 0.5 = tanh(x/2)/2: no cancellation in bf16 (halo rows
+            # are never read)
+            out.rows.mul_(0.5).tanh_().mul_(0.5)
+            return out
+        return out.sigmoid() - 0.5
+
+
+def semantic_inference_3d(ov_classifier_weight, feat_occ, occ_size):
+    """The reference's order (san_in_veon_temporal.py:196-201, 257-259):
+    trilinear-upsample the C-channel feature volume to ``occ_size``, then
+    ``einsum('qc,bczhw->bqzhw')`` with the open-vocabulary classifier."""
+    feat = nn.functional.interpolate(feat_occ, size=tuple(occ_size), mode='trilinear',
+                                     align_corners=False)
+    return torch.einsum('qc,bczhw->bqzhw', ov_classifier_weight, feat)
+
+
+def semantic_inference_3d_fused(ov_classifier_weight, feat_occ, occ_size):
+    """Same logits with the two linear maps swapped: classify at the head's
+    resolution (one GEMM over the voxels: C -> Q classes), then upsample Q
+    channels instead of C (768 -> ~20: the 2 GB upsampled feature volume of the
+    reference is never formed).  Interpolation weights are per-channel and sum
+    to one, the classifier is per-voxel linear, so the results agree up to
+    rounding.  ``feat_occ``: (B,C,Z,Y,X) tensor or the PaddedVolume of
+    ``PredHead3DSem(..., return_volume=True)`` (GEMM on MFMA, fp32 logits)."""
+    W = ov_classifier_weight
+    Q, C = W.shape
+    if isinstance(feat_occ, conv3d_ops.PaddedVolume):
+        vol = feat_occ
+        B, Cv, Z, Y, X = vol.shape
+        assert Cv >= C and C % 64 == 0
+        qp = (Q + 7) // 8 * 8
+        wp = torch.zeros(qp, Cv, device=W.device)
+        wp[:Q, :C] = W.detach().float()
+        logits = torch.zeros(vol.M, qp, dtype=torch.float32, device=W.device)
+        vit_ops.linear_residual_(logits, vol.rows, wp.to(torch.bfloat16).contiguous())
+        low = logits.view(B, Z + 2, Y + 2, X + 2, qp)[:, 1:-1, 1:-1, 1:-1, :Q] \
+            .permute(0, 4, 1, 2, 3)
+    else:
+        low = torch.einsum('qc,bczhw->bqzhw', W, feat_occ)
+    return nn.functional.interpolate(low, size=tuple(occ_size), mode='trilinear',
+                                     align_corners=False)
 
 
 class ResBlock3D(nn.Module):
