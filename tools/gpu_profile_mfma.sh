@@ -16,3 +16,6 @@ echo "body pmc exit $?"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/att_trace -- python3 $A > $OUT/att_trace.log 2>&1
 echo "att trace exit $?"
 find $OUT -name "*.csv" | head -20
+V=$GRAFT_REPO_ROOT/tools/vit_bench.py
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/vit_trace -- python3 $V > $OUT/vit_trace.log 2>&1
+echo "vit trace exit $?"
