@@ -17,7 +17,10 @@ The SAN side adapter and the HSA network are NOT part of this (PyTorch in the re
 throughput of the rows SURVEY section 8 puts on the hot path plus row f1, not a
 full VEON end-to-end number.
 
-    python tools/hotpath_bench.py [vitb|vitl] [--head-bf16] [--graph-clip]
+    python tools/hotpath_bench.py [vitb|vitl] [--head-bf16] [--veon-res] [--graph-clip]
+
+--veon-res: 512x1408 input as configs/veon/* (CLIP sees 705 tokens per camera,
+the lift 32x88 feature maps with D=88); default 256x704 as BASELINE.json.
 """
 import os
 import sys
@@ -49,16 +52,16 @@ def timeit(fn, iters=20):
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith('--')]
     enc = args[0] if args else 'vitb'
-    run(enc, '--head-bf16' in sys.argv, '--graph-clip' in sys.argv)
+    size = (512, 1408) if '--veon-res' in sys.argv else (256, 704)
+    run(enc, '--head-bf16' in sys.argv, '--graph-clip' in sys.argv, size=size)
 
 
 def run(enc='vitb', head_bf16=True, graph_clip=False, dev='cuda:0', iters=20,
-        verbose=True):
+        verbose=True, size=(256, 704)):
     """Build the chain, time its stages and the whole; returns a dict (ms)."""
     def say(*a):
         if verbose:
             print(*a, flush=True)
-    size = (256, 704)
     torch.manual_seed(0)
     cfgs = {'vitb': dict(encoder='vitb', features=128, out_channels=[96, 192, 384, 768]),
             'vitl': dict(encoder='vitl', features=256, out_channels=[256, 512, 1024, 1024])}
