@@ -5,6 +5,7 @@ Tolerance: operands are bf16 on both sides and accumulation is fp32, so the only
 differences are the fp32 summation order and the final bf16 rounding of the
 kernel's output: |got - want| <= 2^-7 * |want| + 2e-3 * rms(want) per element.
 """
+import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
@@ -293,3 +294,45 @@ def test_fused_semantic_inference_on_padded_volume():
     assert got.shape == want.shape == (1, 17, 8, 18, 22)
     rel = ((got - want).norm() / want.norm()).item()
     assert rel < 1.5e-2, rel
+
+
+@pytest.mark.parametrize('seed', range(10))
+def test_conv_random_shapes(seed):
+    """Random small volumes / images and channel counts (all tile families, ragged
+    last tiles, batch > 1, single-voxel planes) against torch in fp64."""
+    rng = np.random.default_rng(4000 + seed)
+    three_d = bool(seed % 2)
+    B = int(rng.integers(1, 4))
+    Cin = int(rng.choice([64, 128, 192]))
+    Cout = int(rng.choice([8, 32, 64, 72, 128, 256, 264]))
+    Z = int(rng.integers(1, 5)) if three_d else 1
+    Y, X = int(rng.integers(1, 24)), int(rng.integers(1, 40))
+    g = torch.Generator().manual_seed(seed)
+    relu = bool(rng.integers(0, 2))
+    use_res = Cin == Cout and bool(rng.integers(0, 2))
+    scale = (torch.rand(Cout, generator=g) + 0.5).to(DEV)
+    shift = torch.randn(Cout, generator=g).to(DEV)
+    if three_d:
+        x = _bf(torch.randn(B, Cin, Z, Y, X, generator=g)).to(DEV)
+        w = _bf(torch.randn(Cout, Cin, 3, 3, 3, generator=g) * (27 * Cin) ** -0.5).to(DEV)
+        want = F.conv3d(x.double(), w.double(), padding=1).float()
+        bc = (1, -1, 1, 1, 1)
+        vol = conv3d_ops.pack(x)
+        out = conv3d_ops.conv3d_k3(vol, conv3d_ops.pack_weight(w), scale, shift,
+                                   resid=vol if use_res else None, relu=relu)
+        got = conv3d_ops.unpack(out)
+    else:
+        x = _bf(torch.randn(B, Cin, Y, X, generator=g)).to(DEV)
+        w = _bf(torch.randn(Cout, Cin, 3, 3, generator=g) * (9 * Cin) ** -0.5).to(DEV)
+        want = F.conv2d(x.double(), w.double(), padding=1).float()
+        bc = (1, -1, 1, 1)
+        img = conv3d_ops.pack_image(x)
+        out = conv3d_ops.conv2d_k3(img, conv3d_ops.pack_weight2d(w), scale, shift,
+                                   resid=img if use_res else None, relu=relu)
+        got = conv3d_ops.unpack_image(out, channels=Cout)
+    want = want * scale.view(bc) + shift.view(bc)
+    if use_res:
+        want = want + x
+    if relu:
+        want = F.relu(want)
+    _close(got, want)
