@@ -70,6 +70,51 @@ __global__ __launch_bounds__(256) void k_layernorm(
   }
 }
 
+// Vector form for d % 256 == 0 (ViT-B/L: 768, 1024): a lane owns float4 chunks
+// c = 4*(i*64 + lane), so the row comes in by 16-byte loads (1 KiB per wave
+// instruction) and leaves by 8-byte bf16x4 stores.  Same arithmetic order per
+// element as k_layernorm except the lane-local partial sums.
+template <int NV>  // float4 chunks per lane = d / 256
+__global__ __launch_bounds__(256) void k_layernorm_v4(
+    const float* __restrict__ x, const float* __restrict__ gamma,
+    const float* __restrict__ beta, bf16_t* __restrict__ out, int T, float eps) {
+  constexpr int d = NV * 256;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= T) return;
+  const float4* xr = reinterpret_cast<const float4*>(x + (int64_t)row * d);
+  float4 v[NV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    v[i] = xr[i * 64 + lane];
+    s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  }
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+  const float mean = s / (float)d;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean,
+                e = v[i].w - mean;
+    q += (a * a + b * b) + (c * c + e * e);
+  }
+  for (int off = 32; off > 0; off >>= 1) q += __shfl_xor(q, off);
+  const float rstd = rsqrtf(q / (float)d + eps);
+  uint2* o = reinterpret_cast<uint2*>(out + (int64_t)row * d);
+  const float4* g4 = reinterpret_cast<const float4*>(gamma);
+  const float4* b4 = reinterpret_cast<const float4*>(beta);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const float4 g = g4[i * 64 + lane], b = b4[i * 64 + lane];
+    o[i * 64 + lane] =
+        uint2{pack_bf16((v[i].x - mean) * rstd * g.x + b.x,
+                        (v[i].y - mean) * rstd * g.y + b.y),
+              pack_bf16((v[i].z - mean) * rstd * g.z + b.z,
+                        (v[i].w - mean) * rstd * g.w + b.w)};
+  }
+}
+
 // ----------------------------------------------------------------------- GEMM
 // (WM*16*MT) x (64*WN) output tile, BK = 64, WM x WN waves, each wave
 // (16*MT) tokens x 64 features = MT x 4 MFMA tiles; the launcher picks
@@ -517,9 +562,19 @@ int veon_vit_layernorm(const float* x, const float* gamma, const float* beta,
   if (T <= 0 || d <= 0 || d > 64 * kLnMaxPerLane || !x || !gamma || !beta ||
       !out_bf16)
     return VEON_ERR_BAD_ARG;
-  hipLaunchKernelGGL(k_layernorm, dim3((unsigned)((T + 3) / 4)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), x, gamma, beta,
-                     static_cast<bf16_t*>(out_bf16), T, d, eps);
+  const dim3 grid((unsigned)((T + 3) / 4));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  bf16_t* o = static_cast<bf16_t*>(out_bf16);
+  const bool vec = al16(x) && al16(gamma) && al16(beta) &&
+                   (reinterpret_cast<uintptr_t>(out_bf16) & 7u) == 0;
+  if (vec && d == 768)
+    hipLaunchKernelGGL(k_layernorm_v4<3>, grid, dim3(256), 0, s, x, gamma, beta, o, T, eps);
+  else if (vec && d == 1024)
+    hipLaunchKernelGGL(k_layernorm_v4<4>, grid, dim3(256), 0, s, x, gamma, beta, o, T, eps);
+  else if (vec && d == 256)
+    hipLaunchKernelGGL(k_layernorm_v4<1>, grid, dim3(256), 0, s, x, gamma, beta, o, T, eps);
+  else
+    hipLaunchKernelGGL(k_layernorm, grid, dim3(256), 0, s, x, gamma, beta, o, T, d, eps);
   return launch_status();
 }
 
