@@ -243,3 +243,35 @@ def test_fused_semantic_inference_equals_reference_order():
     b = semantic_inference_3d_fused(W, feat, (6, 10, 12))
     assert a.shape == b.shape == (2, 17, 6, 10, 12)
     assert torch.allclose(a, b, atol=2e-5, rtol=1e-5)
+
+
+def test_bevstereo_cost_volume_matches_reference_vectors():
+    """DepthNet(stereo=True): gen_grid / calculate_cost_volumn reproduce the
+    reference's own methods (view_transformer.py:543-601, vectors from
+    oracle/tools/gen_golden_stereo.py); the stereo forward runs end to end."""
+    import torch
+    from tests.conftest import load_golden
+    from veon_amd.models.necks.view_transformer import DepthNet
+    g = load_golden('stereo_cost_volume')
+    t = {k: torch.from_numpy(v) for k, v in g.items() if v.ndim > 0}
+    net = DepthNet(16, 32, 8, 7, use_dcn=False, use_aspp=False, stereo=True,
+                   bias=float(g['bias'])).eval()
+    metas = dict(frustum=t['frustum'], post_trans=t['post_trans'],
+                 post_rots=t['post_rots'], k2s_sensor=t['k2s_sensor'],
+                 intrins=t['intrins'], cv_feat_list=[t['prev'], t['curr']],
+                 downsample=16, cv_downsample=4)
+    D, H, W, _ = t['frustum'].shape
+    with torch.no_grad():
+        grid = net.gen_grid(metas, 1, 2, D, H, W, H * 4, W * 4)
+        cv = net.calculate_cost_volumn(metas)
+    assert torch.allclose(grid, t['grid'], atol=1e-5)
+    assert torch.allclose(cv, t['cost_volume'], atol=1e-6)
+    # forward with the cost volume (features at downsample 16 = cv res / 4) and
+    # with the "no previous frame" zeros branch
+    x = torch.randn(2, 16, 2, 3)
+    mlp = torch.randn(1, 2, 27)
+    with torch.no_grad():
+        y = net(x, mlp, metas)
+        metas0 = dict(metas, cv_feat_list=[None, t['curr']])
+        y0 = net(x, mlp, metas0)
+    assert y.shape == y0.shape == (2, 7 + 8, 2, 3)

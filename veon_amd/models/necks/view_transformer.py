@@ -155,18 +155,15 @@ class SELayer(nn.Module):
 
 class DepthNet(nn.Module):
     """Camera-aware depth/context head (view_transformer.py:470-630): same
-    sub-module names, so BEVDepth checkpoints map one to one.  ``use_dcn``
-    needs mmcv's deformable conv; the stereo cost volume (BEVStereo) is not
-    part of the accelerated path and is not implemented."""
+    sub-module names, so BEVDepth / BEVStereo checkpoints map one to one.
+    ``use_dcn`` needs mmcv's deformable conv.  The stereo cost volume
+    (``stereo=True``, :500-512, :543-601) is plain PyTorch (grid_sample), off
+    VEON's path."""
 
     def __init__(self, in_channels, mid_channels, context_channels,
                  depth_channels, use_dcn=True, use_aspp=True, with_cp=False,
                  stereo=False, bias=0.0, aspp_mid_channels=-1):
         super().__init__()
-        if stereo:
-            raise NotImplementedError(
-                'DepthNet(stereo=True): the BEVStereo cost volume is outside '
-                'the accelerated hot path (SURVEY 2 #5)')
         self.reduce_conv = nn.Sequential(
             nn.Conv2d(in_channels, mid_channels, 3, 1, 1),
             nn.BatchNorm2d(mid_channels), nn.ReLU(inplace=True))
@@ -176,7 +173,20 @@ class DepthNet(nn.Module):
         self.depth_se = SELayer(mid_channels)
         self.context_mlp = Mlp(27, mid_channels, mid_channels)
         self.context_se = SELayer(mid_channels)
-        layers = [BasicBlock(mid_channels, mid_channels) for _ in range(3)]
+        depth_in = mid_channels
+        downsample = None
+        if stereo:
+            depth_in += depth_channels
+            downsample = nn.Conv2d(depth_in, mid_channels, 1, 1, 0)
+            cv = []
+            for _ in range(2):
+                cv += [nn.Conv2d(depth_channels, depth_channels, 3, 2, 1),
+                       nn.BatchNorm2d(depth_channels)]
+            self.cost_volumn_net = nn.Sequential(*cv)
+            self.bias = bias
+        layers = [BasicBlock(depth_in, mid_channels, downsample=downsample),
+                  BasicBlock(mid_channels, mid_channels),
+                  BasicBlock(mid_channels, mid_channels)]
         if use_aspp:
             layers.append(ASPP(mid_channels, mid_channels
                                if aspp_mid_channels < 0 else aspp_mid_channels))
@@ -193,14 +203,75 @@ class DepthNet(nn.Module):
         self.with_cp = with_cp
         self.depth_channels = depth_channels
 
+    def gen_grid(self, metas, B, N, D, H, W, hi, wi):
+        """Sampling grid of the previous frame for every (depth, pixel) of the
+        current one (:543-571): un-augment, lift with the candidate depth, move
+        key -> sweep sensor, project, re-augment, normalise to [-1, 1]."""
+        frustum = metas['frustum']
+        points = frustum - metas['post_trans'].view(B, N, 1, 1, 1, 3)
+        points = torch.inverse(metas['post_rots']).view(B, N, 1, 1, 1, 3, 3) \
+            .matmul(points.unsqueeze(-1))
+        points = torch.cat(
+            (points[..., :2, :] * points[..., 2:3, :], points[..., 2:3, :]), 5)
+        rots = metas['k2s_sensor'][:, :, :3, :3].contiguous()
+        trans = metas['k2s_sensor'][:, :, :3, 3].contiguous()
+        combine = rots.matmul(torch.inverse(metas['intrins']))
+        points = combine.view(B, N, 1, 1, 1, 3, 3).matmul(points)
+        points = points + trans.view(B, N, 1, 1, 1, 3, 1)
+        neg_mask = points[..., 2, 0] < 1e-3
+        points = metas['intrins'].view(B, N, 1, 1, 1, 3, 3).matmul(points)
+        points = points[..., :2, :] / points[..., 2:3, :]
+        points = metas['post_rots'][..., :2, :2].view(B, N, 1, 1, 1, 2, 2) \
+            .matmul(points).squeeze(-1)
+        points = points + metas['post_trans'][..., :2].view(B, N, 1, 1, 1, 2)
+        px = points[..., 0] / (wi - 1.0) * 2.0 - 1.0
+        py = points[..., 1] / (hi - 1.0) * 2.0 - 1.0
+        px = torch.where(neg_mask, torch.full_like(px, -2), px)
+        py = torch.where(neg_mask, torch.full_like(py, -2), py)
+        return torch.stack([px, py], dim=-1).view(B * N, D * H, W, 2)
+
+    def calculate_cost_volumn(self, metas):
+        """Group-wise L1 matching cost between the current features and the
+        previous frame's warped to every depth hypothesis, softmax over depth
+        (:573-601)."""
+        prev, curr = metas['cv_feat_list']
+        group_size = 4
+        _, c, hf, wf = curr.shape
+        hi, wi = hf * 4, wf * 4
+        B, N, _ = metas['post_trans'].shape
+        D, H, W, _ = metas['frustum'].shape
+        grid = self.gen_grid(metas, B, N, D, H, W, hi, wi).to(curr.dtype)
+        prev = prev.view(B * N, -1, H, W)
+        curr = curr.view(B * N, -1, H, W)
+        cost = 0
+        wrap_prev = None
+        for fid in range(curr.shape[1] // group_size):
+            sl = slice(fid * group_size, (fid + 1) * group_size)
+            wrap_prev = F.grid_sample(prev[:, sl], grid, align_corners=True,
+                                      padding_mode='zeros')
+            diff = curr[:, sl].unsqueeze(2) - wrap_prev.view(B * N, -1, D, H, W)
+            cost = cost + diff.abs().sum(dim=1)
+        if not self.bias == 0:
+            invalid = wrap_prev[:, 0, ...].view(B * N, D, H, W) == 0
+            cost = torch.where(invalid, cost + self.bias, cost)
+        return (-cost).softmax(dim=1)
+
     def forward(self, x, mlp_input, stereo_metas=None):
-        if stereo_metas is not None:
-            raise NotImplementedError('stereo_metas: see class docstring')
         mlp_input = self.bn(mlp_input.reshape(-1, mlp_input.shape[-1]))
         x = self.reduce_conv(x)
         context = self.context_se(x, self.context_mlp(mlp_input)[..., None, None])
         context = self.context_conv(context)
         depth = self.depth_se(x, self.depth_mlp(mlp_input)[..., None, None])
+        if stereo_metas is not None:
+            if stereo_metas['cv_feat_list'][0] is None:
+                BN, _, H, W = x.shape
+                sf = float(stereo_metas['downsample']) / stereo_metas['cv_downsample']
+                cost_volumn = torch.zeros((BN, self.depth_channels, int(H * sf),
+                                           int(W * sf))).to(x)
+            else:
+                with torch.no_grad():
+                    cost_volumn = self.calculate_cost_volumn(stereo_metas)
+            depth = torch.cat([depth, self.cost_volumn_net(cost_volumn)], dim=1)
         if self.with_cp:
             depth = checkpoint(self.depth_conv, depth)
         else:
