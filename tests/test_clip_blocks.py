@@ -113,3 +113,20 @@ def test_cross_attn_with_self_bias_equals_augmented_softmax():
         ref = x + attn_out
         ref = ref + blk.mlp(blk.ln_2(ref))
     torch.testing.assert_close(got, ref, rtol=1e-4, atol=1e-5)
+
+
+def test_cross_attention_with_self_logit_matches_reference_vectors():
+    """cross_attn_with_self_bias vs the reference's own attn_helper.py run on a
+    seeded nn.MultiheadAttention (oracle/tools/gen_golden_clip_attn.py): float
+    bias, no mask and boolean mask."""
+    from tests.conftest import load_golden
+    from veon_amd.models.semantic_net.clip_blocks import cross_attn_with_self_bias
+    g = load_golden('clip_cross_attn')
+    t = {k: torch.from_numpy(v) for k, v in g.items()}
+    mha = torch.nn.MultiheadAttention(64, 4).eval()
+    mha.load_state_dict({k[4:]: v for k, v in t.items() if k.startswith('mha/')})
+    with torch.no_grad():
+        for mask, key in ((t['bias'], 'out_bias'), (None, 'out_none'),
+                          (t['bool_mask'], 'out_bool')):
+            got = cross_attn_with_self_bias(mha, t['q'], t['mem'], t['mem'], attn_mask=mask)
+            assert torch.allclose(got, t[key], atol=2e-6), key
