@@ -130,3 +130,28 @@ def test_cross_attention_with_self_logit_matches_reference_vectors():
                           (t['bool_mask'], 'out_bool')):
             got = cross_attn_with_self_bias(mha, t['q'], t['mem'], t['mem'], attn_mask=mask)
             assert torch.allclose(got, t[key], atol=2e-6), key
+
+
+def test_trunk_wiring_matches_reference_feature_extractor():
+    """ClipVisualTrunk vs the reference's own FeatureExtractor.forward
+    (clip_utils/visual.py:57-91, run by oracle/tools/gen_golden_clip_trunk.py
+    around the same sub-modules): patchify, class token, position-embedding
+    resize (4x4 -> 2x3), ln_pre, LND layout and the per-block outputs, in
+    training-free eval mode for both the conv and the GEMM patchify."""
+    from tests.conftest import load_golden
+    from veon_amd.models.semantic_net import ClipVisualTrunk
+    g = load_golden('clip_trunk_tiny')
+    trunk = ClipVisualTrunk(image_size=64, patch_size=16, width=64, layers=2, heads=1).eval()
+    trunk.load_state_dict({k[3:]: torch.from_numpy(v) for k, v in g.items()
+                           if k.startswith('sd/')})
+    x = torch.from_numpy(g['x'])
+    for ctx in (torch.no_grad, torch.enable_grad):   # GEMM patchify / conv1 patchify
+        with ctx():
+            outs, hw = trunk(x)
+        assert tuple(hw) == tuple(int(v) for v in g['hw'])
+        for i in range(3):
+            t = outs[i].detach()                      # (L, N, D)
+            n, c = t.shape[1], t.shape[2]
+            feat = t[1:].permute(1, 2, 0).reshape(n, c, *hw)
+            assert torch.allclose(feat, torch.from_numpy(g['feat_%d' % i]), atol=2e-5), i
+            assert torch.allclose(t[0:1], torch.from_numpy(g['cls_%d' % i]), atol=2e-5), i
