@@ -155,3 +155,59 @@ def test_trunk_wiring_matches_reference_feature_extractor():
             feat = t[1:].permute(1, 2, 0).reshape(n, c, *hw)
             assert torch.allclose(feat, torch.from_numpy(g['feat_%d' % i]), atol=2e-5), i
             assert torch.allclose(t[0:1], torch.from_numpy(g['cls_%d' % i]), atol=2e-5), i
+
+
+def _head_from_golden(g, device='cpu'):
+    from veon_amd.models.semantic_net import ClipRecHead
+    from veon_amd.models.semantic_net.clip_blocks import ResidualAttentionBlock
+    t = {k: torch.from_numpy(v) for k, v in g.items()}
+    blocks = torch.nn.ModuleList([ResidualAttentionBlock(64, 1) for _ in range(5)])
+    blocks.load_state_dict({k[7:]: v for k, v in t.items() if k.startswith('blocks/')})
+    ln_post = torch.nn.LayerNorm(64)
+    ln_post.load_state_dict({k[8:]: v for k, v in t.items() if k.startswith('ln_post/')})
+    head = ClipRecHead(blocks, ln_post, torch.nn.Parameter(t['proj']),
+                       first_layer_idx=int(t['first']), sos_token_num=3)
+    return head.to(device).eval(), {k: v.to(device) for k, v in t.items()}
+
+
+def test_rec_head_matches_reference_vectors():
+    """ClipRecHead vs the reference's own RecWithAttnbiasHead
+    (clip_utils/visual.py:112-292, oracle/tools/gen_golden_clip_head.py): the
+    SOS-token forward with cross attention, and update_remaining_clip_feats with
+    offsets + dense attention biases."""
+    from tests.conftest import load_golden
+    g = load_golden('clip_head_tiny')
+    head, t = _head_from_golden(g)
+    first = int(t['first'])
+    feats = {first: t['feat'], '%d_cls_token' % first: t['cls']}
+    with torch.no_grad():
+        sos = head(feats, [t['attn_bias']], normalize=True)
+        assert torch.allclose(sos, t['sos'], atol=2e-5)
+        outs = {first: t['feat'].clone(), '%d_cls_token' % first: t['cls'].clone()}
+        attns = [t['attn_%d' % i] for i in range(3)]
+        head.update_remaining_clip_feats(outs, t['offsets'], attns)
+    for i in range(first + 1, 6):
+        assert torch.allclose(outs[i], t['out_%d' % i], atol=5e-5), i
+        assert torch.allclose(outs['%d_cls_token' % i], t['out_cls_%d' % i], atol=5e-5), i
+    assert torch.allclose(outs['clip_feat_proj'], t['clip_feat_proj'], atol=5e-5)
+
+
+@pytest.mark.gpu
+def test_rec_head_tail_blocks_on_mfma():
+    """update_remaining_clip_feats on a ROCm device: the tail blocks (with their
+    dense masks) run through veon_vit_block; result within bf16 tolerance of the
+    reference vectors."""
+    from tests.conftest import load_golden
+    from veon_amd import _lib
+    g = load_golden('clip_head_tiny')
+    head, t = _head_from_golden(g, 'cuda:0')
+    first = int(t['first'])
+    outs = {first: t['feat'].clone(), '%d_cls_token' % first: t['cls'].clone()}
+    attns = [t['attn_%d' % i] for i in range(3)]
+    before = _lib.CALLS.get('veon_vit_block', 0)
+    with torch.no_grad():
+        head.update_remaining_clip_feats(outs, t['offsets'], attns)
+    assert _lib.CALLS.get('veon_vit_block', 0) - before == 3
+    want = t['clip_feat_proj']
+    rel = ((outs['clip_feat_proj'] - want).norm() / want.norm()).item()
+    assert rel < 2e-2, rel

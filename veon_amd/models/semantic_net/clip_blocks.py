@@ -13,10 +13,13 @@ This module restates the published block
 with ``nn.MultiheadAttention``'s packed ``in_proj_weight`` / ``in_proj_bias`` /
 ``out_proj`` and ``mlp.c_fc`` / ``mlp.c_proj`` parameter names (what an
 ``open_clip`` checkpoint holds), QuickGELU for OpenAI weights.
-**Parity unpinned**: ``open_clip`` is not installed and the reference holds no
-vectors for it; tests compare against ``torch.nn.MultiheadAttention`` semantics.
-The 100-query cross attention with the extra "self" logit
-(attn_helper.py:34-300) stays in PyTorch for now.
+**Block parity unpinned**: ``open_clip`` is not installed and the reference holds
+no vectors for it; tests compare against ``torch.nn.MultiheadAttention``
+semantics.  What the reference itself owns around the block IS pinned by vectors
+generated from its unmodified files (oracle/tools/gen_golden_clip_*.py): the
+query-token cross attention with the extra "self" logit (attn_helper.py:34-300,
+PyTorch here: 100 queries are not a hot loop), the trunk wiring
+(``FeatureExtractor``) and the recognition head (``RecWithAttnbiasHead``).
 """
 from collections import OrderedDict
 
@@ -252,3 +255,152 @@ class ClipVisualTrunk(nn.Module):
         blocks = list(self.resblocks if last_layer_idx == -1
                       else self.resblocks[:last_layer_idx])
         return [t] + run_blocks(blocks, t, attn_masks, self._hip_cache), hw
+
+
+class ClipRecHead(nn.Module):
+    """Mirror of ``RecWithAttnbiasHead`` (clip_utils/visual.py:112-292) for the
+    configuration VEON uses (``cross_attn=True``): the tail blocks
+    ``resblocks[first_layer_idx:]`` of the CLIP visual transformer, ``ln_post``
+    and ``proj``.
+
+    * ``forward(features, attn_bias)``: the SOS/query tokens attend over the
+      patch tokens of layer ``first_layer_idx`` through ``cross_attn_layer``
+      (per-head additive bias + self logit) while the patch tokens run through
+      the plain blocks; returns the projected query tokens (:164-216).
+    * ``update_remaining_clip_feats(clip_outputs, offsets, attns)``: the tail
+      blocks once more over all tokens, with feature offsets added before the
+      first and the middle block and a dense additive (B*heads, L+1, L+1) mask
+      per block; fills the per-layer outputs and ``clip_feat_proj`` (:258-285).
+      On a ROCm device at inference the blocks run on the MFMA kernels
+      (``run_blocks``).
+
+    ``features`` / ``clip_outputs``: dict with ``[i]`` = (N,C,h,w) patch map and
+    ``['%d_cls_token' % i]`` = (1,N,C), as ``ClipOutput`` in the reference.
+    """
+
+    def __init__(self, resblocks, ln_post, proj, first_layer_idx=0,
+                 sos_token_format='cls_token', sos_token_num=1,
+                 downsample_method='bilinear'):
+        super().__init__()
+        if first_layer_idx < 0:
+            raise NotImplementedError('first_layer_idx < 0 is not implemented yet.')
+        self.first_layer_idx = first_layer_idx
+        self.resblocks = nn.ModuleList(list(resblocks)[first_layer_idx:])
+        self.ln_post = ln_post
+        self.proj = proj                       # (width, output_dim) parameter
+        self.sos_token_format = sos_token_format
+        self.sos_token_num = sos_token_num
+        self.downsample_method = downsample_method
+        if sos_token_format in ('learnable_token', 'pos_embedding'):
+            self.sos_token = nn.Parameter(
+                torch.randn(sos_token_num, 1, proj.shape[0]) * 0.02)
+        self._hip_cache = {}
+
+    def train(self, mode=True):
+        self._hip_cache = {}
+        return super().train(mode)
+
+    @staticmethod
+    def _save(outputs, idx, tokens, hw):
+        l, n, c = tokens.shape
+        outputs[idx] = tokens[1:].permute(1, 2, 0).reshape(n, c, *hw)
+        outputs['%d_cls_token' % idx] = tokens[0:1]
+
+    def _build_attn_biases(self, attn_biases, target_shape):
+        """[N, heads|1, num_sos, H, W] per entry -> (N*heads, num_sos, h*w)
+        (:218-256, the cross_attn branch)."""
+        out = []
+        true_heads = self.resblocks[0].attn.num_heads
+        for ab in attn_biases:
+            n, num_head, num_sos, h, w = ab.shape
+            ab = ab.reshape(n, num_head * num_sos, h, w)
+            if self.downsample_method in ('bicubic', 'bilinear', 'nearest'):
+                ab = F.interpolate(ab, size=target_shape, mode=self.downsample_method,
+                                   align_corners=False)
+            elif self.downsample_method == 'avg':
+                ab = F.adaptive_avg_pool2d(ab, output_size=target_shape)
+            else:
+                ab = F.adaptive_max_pool2d(ab, output_size=target_shape)
+            ab = ab.reshape(n, num_head, num_sos, *target_shape)
+            assert num_head in (1, true_heads), 'num_head=%d is not supported.' % num_head
+            if num_head == 1:
+                ab = ab.repeat(1, true_heads, 1, 1, 1)
+            out.append(ab.reshape(n * true_heads, num_sos, -1))
+        if len(out) == 1:
+            out = [out[0] for _ in self.resblocks]
+        return out
+
+    def forward(self, features, attn_bias, normalize=False, clip_outputs=None):
+        k0 = self.first_layer_idx
+        cls_token = features['%d_cls_token' % k0]        # 1,n,c
+        pix = features[k0]                               # n,c,h,w
+        n, c, h, w = pix.shape
+        x = torch.cat([cls_token, pix.reshape(n, c, -1).permute(2, 0, 1)])
+        if self.sos_token_format == 'cls_token':
+            sos = cls_token.repeat(self.sos_token_num, 1, 1)
+        elif self.sos_token_format == 'learnable_token':
+            sos = self.sos_token.expand(-1, n, -1)
+        else:
+            sos = self.sos_token.expand(-1, n, -1) + cls_token
+        biases = self._build_attn_biases(attn_bias, (h, w))
+        last = len(self.resblocks) - 1
+        for i, blk in enumerate(self.resblocks):
+            sos = cross_attn_layer(blk, sos, x[1:], biases[i])
+            if clip_outputs is None and i < last:
+                x = blk(x)
+            elif clip_outputs is not None:
+                x = blk(x)
+                self._save(clip_outputs, i + k0 + 1, x, (h, w))
+        sos = self.ln_post(sos.permute(1, 0, 2))
+        if self.proj is not None:
+            sos = sos @ self.proj
+        if normalize:
+            sos = F.normalize(sos, dim=-1)
+        if clip_outputs is not None:
+            clip_outputs['clip_feat_proj'] = torch.einsum(
+                'bchw,cd->bdhw', clip_outputs[len(self.resblocks) + k0], self.proj)
+            return sos, clip_outputs
+        return sos
+
+    @staticmethod
+    def build_attn_bias(attn):
+        """(B, heads, L, L) patch-to-patch bias -> (B*heads, L+1, L+1) with a
+        zero row / column for the class token (:287-292)."""
+        B, H, L, _ = attn.shape
+        new = torch.zeros((B, H, L + 1, L + 1), device=attn.device, dtype=attn.dtype)
+        new[:, :, 1:, 1:] = attn
+        return new.reshape(B * H, L + 1, L + 1)
+
+    def update_remaining_clip_feats(self, clip_outputs, offsets=None, attns=None):
+        k0 = self.first_layer_idx
+        cls_token = clip_outputs['%d_cls_token' % k0]
+        x = clip_outputs[k0]
+        hw = tuple(x.shape[2:])
+        x = x.reshape(x.shape[0], x.shape[1], -1).permute(2, 0, 1)
+        x = torch.cat([cls_token, x], dim=0)
+        nblk = len(self.resblocks)
+        # the offsets (added before block 0 and before block nblk // 2) split the
+        # tail into runs of blocks that go to the MFMA path back to back
+        cuts = [0, nblk] if offsets is None else sorted({0, nblk // 2, nblk})
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            if offsets is not None:
+                if a == 0:
+                    x = torch.cat([x[:1], x[1:] + offsets[0].permute(1, 0, 2)], dim=0)
+                if a == nblk // 2:
+                    x = torch.cat([x[:1], x[1:] + offsets[1].permute(1, 0, 2)], dim=0)
+                    if a > 0:
+                        # reference behaviour kept: ClipOutput.save stores a VIEW
+                        # of the block output, and the in-place offset add of the
+                        # next iteration (:268-271) writes through it, so the
+                        # saved map of the block before the middle carries the
+                        # second offset too
+                        self._save(clip_outputs, a + k0, x, hw)
+            masks = None if attns is None else \
+                [self.build_attn_bias(attns[t]) for t in range(a, b)]
+            outs = run_blocks(list(self.resblocks)[a:b], x, masks, self._hip_cache)
+            for t, o in zip(range(a, b), outs):
+                self._save(clip_outputs, t + k0 + 1, o, hw)
+            x = outs[-1]
+        clip_outputs['clip_feat_proj'] = torch.einsum(
+            'bchw,cd->bdhw', clip_outputs[nblk + k0], self.proj)
+        return clip_outputs
