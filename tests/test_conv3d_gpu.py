@@ -336,3 +336,49 @@ def test_conv_random_shapes(seed):
     if relu:
         want = F.relu(want)
     _close(got, want)
+
+
+def test_align_net_decoder_against_reference_vectors():
+    """The whole occupancy decoder (depth prep -> CatFusionLift -> lift + max-pool
+    -> ResBlock3D x2 -> heads) vs the reference's own AlignNetOcc3D run on CPU
+    (oracle/tools/gen_golden_align_net.py).  Lifted volume: fp32, differs from
+    the reference's index_add_ order only; decoder outputs: fp32 module path
+    tight, MFMA fast path within bf16 tolerance."""
+    from tests.conftest import load_golden
+    from veon_amd.models import build_neck
+    from veon_amd.models.semantic_net import AlignNetOcc3D
+    g = load_golden('align_net_tiny')
+    t = {k: torch.from_numpy(v).to(DEV) for k, v in g.items()}
+    net = AlignNetOcc3D(clip_dim=32, hsa_dim=16, embed_dim=64, clip_outdim=24,
+                        layer_lifting_map=['2->0->0'], fusion_type='cat_fusion',
+                        layer_depth=2)
+    net.load_state_dict({k[3:]: v for k, v in t.items() if k.startswith('sd/')})
+    grid = {'x': [-10.0, 10.0, 1.0], 'y': [-10.0, 10.0, 1.0], 'z': [-1.0, 3.0, 1.0],
+            'depth': [1.0, 13.0, 1.0]}
+    vt = build_neck(dict(type='LSSViewTransformerRaw', grid_config=grid,
+                         input_size=(64, 176), downsample=16, out_channels=64,
+                         collapse_z=False, ds_feat=[2, 2, 2]))
+    net.lss_view_transformer = vt
+    net.num_frame, net.num_camera = 1, 2
+    net = net.to(DEV).eval()
+    metas = [t['s2e'], t['e2g'], t['intr'], t['pr'], t['pt'], t['bda'][None]]
+    clip = {1: t['clip1'], 2: t['clip2']}
+    sem_feat = torch.zeros(2, 8, 4, 11, device=DEV)
+    with torch.no_grad():
+        lifted = net.forward_early(sem_feat, clip, [t['supp']], t['metric'], metas)
+        torch.testing.assert_close(lifted, t['lifted'], rtol=1e-4, atol=1e-4)
+        before = dict(_lib.CALLS)
+        fast = net(sem_feat, clip, [t['supp']], t['metric'], metas)
+        ran = {k for k, v in _lib.CALLS.items() if v > before.get(k, 0)}
+        assert {'veon_bev_pool_v2_fwd_maxpool_padded', 'veon_conv3d_k3_bf16',
+                'veon_vit_gemm'} <= ran, ran
+        net.use_hip = False
+        for m in (net.occupancy_pred, net.feat_pred):
+            m._hip_ok = lambda x: False
+        slow = net(sem_feat, clip, [t['supp']], t['metric'], metas)
+    for key in ('bin_occ', 'feat_occ'):
+        want = t[key]
+        rel_slow = ((slow[key] - want).norm() / want.norm()).item()
+        rel_fast = ((fast[key] - want).norm() / want.norm()).item()
+        assert rel_slow < 1e-3, (key, rel_slow)
+        assert rel_fast < 2.5e-2, (key, rel_fast)

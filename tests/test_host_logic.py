@@ -275,3 +275,22 @@ def test_bevstereo_cost_volume_matches_reference_vectors():
         metas0 = dict(metas, cv_feat_list=[None, t['curr']])
         y0 = net(x, mlp, metas0)
     assert y.shape == y0.shape == (2, 7 + 8, 2, 3)
+
+
+def test_fusion_layer_and_decoder_state_dict_match_reference_vectors():
+    """CatFusionLift reproduces the reference layer (layers.py:154-199) and the
+    AlignNetOcc3D mirror loads the reference decoder's state_dict strictly
+    (oracle/tools/gen_golden_align_net.py)."""
+    import torch
+    from tests.conftest import load_golden
+    from veon_amd.models.semantic_net import AlignNetOcc3D
+    g = load_golden('align_net_tiny')
+    t = {k: torch.from_numpy(v) for k, v in g.items()}
+    net = AlignNetOcc3D(clip_dim=32, hsa_dim=16, embed_dim=64, clip_outdim=24,
+                        layer_lifting_map=['2->0->0'], fusion_type='cat_fusion',
+                        layer_depth=2).eval()
+    net.load_state_dict({k[3:]: v for k, v in t.items() if k.startswith('sd/')},
+                        strict=True)
+    with torch.no_grad():
+        got = net.fusion_layers['layer_0'](t['supp'], t['clip2'], (4, 11))
+    assert torch.allclose(got, t['cat_fusion_out'], atol=1e-5)
