@@ -338,7 +338,8 @@ int veon_vit_block(float *x, const veon_vit_block_weights *w,
  * writes guard rows).  w: [Cout][3][3][3][Cin] bf16 (torch's
  * weight.permute(0,2,3,4,1)).  y = conv(in)*scale[n] + shift[n] (eval-mode
  * BatchNorm folded by the caller; either may be NULL), + resid (optional,
- * padded layout, Cout channels), ReLU if `relu`; halo rows of `out` are written
+ * padded layout, Cout channels), then `relu` = 0 nothing / 1 ReLU / 2 GELU (erf);
+ * halo rows of `out` are written
  * as zeros so `out` is a valid padded input of the next conv.  Cin % 64 == 0,
  * Cout % 8 == 0.  out must not alias in.
  */

@@ -382,3 +382,23 @@ def test_align_net_decoder_against_reference_vectors():
         rel_fast = ((fast[key] - want).norm() / want.norm()).item()
         assert rel_slow < 1e-3, (key, rel_slow)
         assert rel_fast < 2.5e-2, (key, rel_fast)
+
+
+def test_hsa_network_convblocks_on_mfma():
+    """HighresSideAdaptorNetwork with conv_dtype = bf16: the ConvBlocks (bias +
+    GELU fused) run on the 2-D MFMA conv kernel; outputs within bf16 tolerance of
+    the reference vectors (the attention biases are Gram matrices of the head
+    output, so their error is about twice the feature error)."""
+    from tests.conftest import load_golden
+    from tests.test_host_logic import _hsa_from_golden
+    net, t = _hsa_from_golden(load_golden('hsa_tiny'), DEV)
+    net.set_conv_dtype(torch.bfloat16)
+    before = _lib.CALLS.get('veon_conv2d_k3_bf16', 0)
+    with torch.no_grad():
+        cb = net.hsa_net_body[0].ff(t['tokens'], (4, 6))
+        _, attns, supp = net(t['image'], {1: t['clip1'], 2: t['clip2']})
+    assert _lib.CALLS.get("veon_conv2d_k3_bf16", 0) - before == 2 + 6
+    for got, key, tol in ((cb, 'convblock_out', 2e-2), (supp, 'supp', 3e-2),
+                          (attns, 'attns', 6e-2)):
+        rel = ((got - t[key]).norm() / t[key].norm()).item()
+        assert rel < tol, (key, rel)

@@ -294,3 +294,31 @@ def test_fusion_layer_and_decoder_state_dict_match_reference_vectors():
     with torch.no_grad():
         got = net.fusion_layers['layer_0'](t['supp'], t['clip2'], (4, 11))
     assert torch.allclose(got, t['cat_fusion_out'], atol=1e-5)
+
+
+def _hsa_from_golden(g, device='cpu'):
+    import torch
+    from veon_amd.models.semantic_net.hsa_network import HighresSideAdaptorNetwork
+    t = {k: torch.from_numpy(v).to(device) for k, v in g.items()}
+    net = HighresSideAdaptorNetwork.build(
+        dim=64, clip_dim=32, mlp_dim=64, input_size=(32, 48), patch_shape=(8, 8),
+        num_heads=2, fusion_map=('0->1->1', '1->2->-1'), manip_dim_head=8,
+        manip_attn_layers=3, manip_add_layers=2, manip_supp_dim=16)
+    net.load_state_dict({k[3:]: v for k, v in t.items() if k.startswith('sd/')},
+                        strict=True)
+    return net.to(device).eval(), t
+
+
+def test_hsa_network_matches_reference_vectors():
+    """HighresSideAdaptorNetwork mirror vs the reference's own
+    highres_side_adaptor.py (oracle/tools/gen_golden_hsa.py): strict state_dict,
+    ConvBlock, attention biases and supp features."""
+    import torch
+    from tests.conftest import load_golden
+    net, t = _hsa_from_golden(load_golden('hsa_tiny'))
+    with torch.no_grad():
+        cb = net.hsa_net_body[0].ff(t['tokens'], (4, 6))
+        _, attns, supp = net(t['image'], {1: t['clip1'], 2: t['clip2']})
+    assert torch.allclose(cb, t['convblock_out'], atol=1e-5)
+    assert torch.allclose(attns, t['attns'], atol=2e-4, rtol=1e-4)
+    assert torch.allclose(supp, t['supp'], atol=1e-5)

@@ -162,10 +162,14 @@ def pack_weight2d(w, pad_out_to=8):
     return wp.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16)
 
 
+_ACT = {None: 0, 'none': 0, 'relu': 1, 'gelu': 2}
+
+
 def conv2d_k3(img, w_packed, scale=None, shift=None, resid=None, relu=False,
-              out=None):
+              out=None, act=None):
     """3x3 stride-1 pad-1 convolution on a PaddedImage with the fused epilogue
-    ``relu?(conv*scale + shift + resid?)`` -> PaddedImage."""
+    ``act(conv*scale + shift + resid?)`` -> PaddedImage; ``act`` in none / relu /
+    gelu (``relu=True`` is shorthand for act='relu')."""
     dev = _lib.require_device(img.storage, w_packed)
     B, Cin, Y, X = img.shape
     Cout = w_packed.shape[0]
@@ -180,7 +184,7 @@ def conv2d_k3(img, w_packed, scale=None, shift=None, resid=None, relu=False,
         st = _lib.lib().veon_conv2d_k3_bf16(
             _lib.ptr(img.rows), _lib.ptr(w_packed), _lib.ptr(scale), _lib.ptr(shift),
             _lib.ptr(None if resid is None else resid.rows), _lib.ptr(out.rows),
-            B, Y, X, Cin, Cout, 1 if relu else 0, _lib.stream_ptr(dev))
+            B, Y, X, Cin, Cout, 1 if relu else _ACT[act], _lib.stream_ptr(dev))
     _lib.check(st, 'veon_conv2d_k3_bf16')
     return out
 

@@ -21,7 +21,8 @@
 // per-lane clamps in the k-loop.
 //
 // Epilogue (fused, fp32): y = acc*scale[n] + shift[n] (BatchNorm3d in eval mode),
-// optional + residual (bf16, same padded layout), optional ReLU, -> bf16.
+// optional + residual (bf16, same padded layout), optional ReLU or GELU(erf),
+// -> bf16.
 #include "mfma_common.h"
 
 namespace {
@@ -29,7 +30,7 @@ namespace {
 constexpr int CBK = 64;
 
 // Tile = (WM*16*MT) voxels x (64*WN) features, WM x WN waves of (16*MT) x 64 each.
-template <int WM, int WN, int MT, bool RELU, bool RESID>
+template <int WM, int WN, int MT, int ACT, bool RESID>
 __global__ __launch_bounds__(64 * WM * WN) void k_conv3d_k3(
     const bf16_t* __restrict__ in, const bf16_t* __restrict__ W,
     const float* __restrict__ scale, const float* __restrict__ shift,
@@ -200,7 +201,8 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv3d_k3(
       }
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        if (RELU) v[k] = fmaxf(v[k], 0.f);
+        if (ACT == 1) v[k] = fmaxf(v[k], 0.f);
+        if (ACT == 2) v[k] = gelu_erf(v[k]);
         if (!interior) v[k] = 0.f;
       }
       const uint2 o = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
@@ -380,8 +382,12 @@ static int conv_k3_impl(int kd, const void* in_padded, const void* w_bf16,
   static const Tile wide[] = {{4, 4, 3}, {4, 4, 4}, {3, 4, 7}};   // 192/256/336 x 256
   static const Tile narrow[] = {{4, 2, 1}, {4, 2, 2}};             // 64/128 x 128, 8 waves
   static const Tile slim[] = {{8, 1, 1}, {8, 1, 2}};               // 128/256 x 64, 8 waves
-  const bool is_wide = Cout >= 256;
-  const Tile* cands = is_wide ? wide : (Cout <= 64 ? slim : narrow);
+  static const Tile mid[] = {{4, 3, 2}, {4, 3, 3}};                // 128/192 x 192, 12 waves
+  // 192-wide tiles when they divide the features and 256-wide ones do not
+  // (e.g. 384 = 2 x 192 exactly, but 256 + a half-empty second column)
+  const bool is_mid = Cout % 192 == 0 && Cout % 256 != 0;
+  const bool is_wide = !is_mid && Cout >= 256;
+  const Tile* cands = is_mid ? mid : is_wide ? wide : (Cout <= 64 ? slim : narrow);
   const int ncand = is_wide ? 3 : 2;
   const int64_t active = (int64_t)B * Z * (Y + 2) * (X + 2);  // rows off the z-halo
   int wm = cands[0].wm, wn = cands[0].wn, mt = cands[0].mt;
@@ -390,7 +396,7 @@ static int conv_k3_impl(int kd, const void* in_padded, const void* w_bf16,
     const int64_t rows = cands[i].wm * 16 * cands[i].mt;
     const int64_t cols = (Cout + 64 * cands[i].wn - 1) / (64 * cands[i].wn);
     const int64_t tiles = ((active + rows - 1) / rows + B) * cols;  // + straddlers
-    const int64_t slots = is_wide ? kNumCU : 2 * kNumCU;  // resident workgroups
+    const int64_t slots = (is_wide || is_mid) ? kNumCU : 2 * kNumCU;  // resident workgroups
     const int64_t cost = ((tiles + slots - 1) / slots) * rows;
     if (best < 0 || cost < best) {
       best = cost;
@@ -406,33 +412,39 @@ static int conv_k3_impl(int kd, const void* in_padded, const void* w_bf16,
   const bf16_t* R = static_cast<const bf16_t*>(resid_padded);
   bf16_t* O = static_cast<bf16_t*>(out_padded);
   const int planes = B * (Z + 2 * pz);
-#define VEON_LAUNCH_CONV(WM, WN, MT, RELU, RESID)                              \
+#define VEON_LAUNCH_CONV(WM, WN, MT, ACT, RESID)                              \
   do {                                                                         \
     constexpr int lds =                                                        \
         2 * (WM * 16 * MT + 64 * WN) * CBK * (int)sizeof(bf16_t);              \
     static const hipError_t attr = hipFuncSetAttribute(                        \
-        reinterpret_cast<const void*>(&k_conv3d_k3<WM, WN, MT, RELU, RESID>),  \
+        reinterpret_cast<const void*>(&k_conv3d_k3<WM, WN, MT, ACT, RESID>),  \
         hipFuncAttributeMaxDynamicSharedMemorySize, lds);                      \
     if (attr != hipSuccess) return VEON_ERR_LAUNCH;                            \
-    hipLaunchKernelGGL((k_conv3d_k3<WM, WN, MT, RELU, RESID>), grid,           \
+    hipLaunchKernelGGL((k_conv3d_k3<WM, WN, MT, ACT, RESID>), grid,           \
                        dim3(64 * WM * WN), lds, s, I, Wt, scale, shift, R, O,  \
                        planes, Z + 2 * pz, Y + 2, X + 2, Cin, Cout, kd);       \
   } while (0)
 #define VEON_TILE_IS(a, b, c) (wm == a && wn == b && mt == c)
-#define VEON_LAUNCH_CONV_T(RELU, RESID)                                        \
+#define VEON_LAUNCH_CONV_T(ACT, RESID)                                        \
   do {                                                                         \
-    if (VEON_TILE_IS(3, 4, 7)) VEON_LAUNCH_CONV(3, 4, 7, RELU, RESID);         \
-    else if (VEON_TILE_IS(4, 4, 3)) VEON_LAUNCH_CONV(4, 4, 3, RELU, RESID);    \
-    else if (VEON_TILE_IS(4, 4, 4)) VEON_LAUNCH_CONV(4, 4, 4, RELU, RESID);    \
-    else if (VEON_TILE_IS(4, 2, 2)) VEON_LAUNCH_CONV(4, 2, 2, RELU, RESID);    \
-    else if (VEON_TILE_IS(8, 1, 1)) VEON_LAUNCH_CONV(8, 1, 1, RELU, RESID);    \
-    else if (VEON_TILE_IS(8, 1, 2)) VEON_LAUNCH_CONV(8, 1, 2, RELU, RESID);    \
-    else VEON_LAUNCH_CONV(4, 2, 1, RELU, RESID);                               \
+    if (VEON_TILE_IS(3, 4, 7)) VEON_LAUNCH_CONV(3, 4, 7, ACT, RESID);         \
+    else if (VEON_TILE_IS(4, 4, 3)) VEON_LAUNCH_CONV(4, 4, 3, ACT, RESID);    \
+    else if (VEON_TILE_IS(4, 4, 4)) VEON_LAUNCH_CONV(4, 4, 4, ACT, RESID);    \
+    else if (VEON_TILE_IS(4, 2, 2)) VEON_LAUNCH_CONV(4, 2, 2, ACT, RESID);    \
+    else if (VEON_TILE_IS(4, 3, 2)) VEON_LAUNCH_CONV(4, 3, 2, ACT, RESID);    \
+    else if (VEON_TILE_IS(4, 3, 3)) VEON_LAUNCH_CONV(4, 3, 3, ACT, RESID);    \
+    else if (VEON_TILE_IS(8, 1, 1)) VEON_LAUNCH_CONV(8, 1, 1, ACT, RESID);    \
+    else if (VEON_TILE_IS(8, 1, 2)) VEON_LAUNCH_CONV(8, 1, 2, ACT, RESID);    \
+    else VEON_LAUNCH_CONV(4, 2, 1, ACT, RESID);                               \
   } while (0)
-  if (relu) {
-    if (R) VEON_LAUNCH_CONV_T(true, true); else VEON_LAUNCH_CONV_T(true, false);
+  if (relu == 1) {
+    if (R) VEON_LAUNCH_CONV_T(1, true); else VEON_LAUNCH_CONV_T(1, false);
+  } else if (relu == 2) {
+    if (R) VEON_LAUNCH_CONV_T(2, true); else VEON_LAUNCH_CONV_T(2, false);
+  } else if (relu == 0) {
+    if (R) VEON_LAUNCH_CONV_T(0, true); else VEON_LAUNCH_CONV_T(0, false);
   } else {
-    if (R) VEON_LAUNCH_CONV_T(false, true); else VEON_LAUNCH_CONV_T(false, false);
+    return VEON_ERR_BAD_ARG;
   }
 #undef VEON_LAUNCH_CONV_T
 #undef VEON_TILE_IS

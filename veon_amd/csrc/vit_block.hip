@@ -129,21 +129,6 @@ constexpr int BK = 64;
 enum { EPI_BF16 = 0, EPI_GELU = 1, EPI_QUICKGELU = 2, EPI_RESID = 3,
        EPI_AFFINE = 4, EPI_AFFINE_RELU = 5 };
 
-// erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below the bf16
-// rounding of the output): one rcp, one exp, five FMAs instead of libm's erff.
-__device__ __forceinline__ float erf_as(float x) {
-  const float ax = fabsf(x);
-  const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.f));
-  float p = fmaf(1.061405429f, t, -1.453152027f);
-  p = fmaf(p, t, 1.421413741f);
-  p = fmaf(p, t, -0.284496736f);
-  p = fmaf(p, t, 0.254829592f);
-  const float y = 1.f - p * t * __expf(-ax * ax);
-  return copysignf(y, x);
-}
-__device__ __forceinline__ float gelu_erf(float x) {
-  return 0.5f * x * (1.f + erf_as(x * 0.70710678118654752f));
-}
 __device__ __forceinline__ float quick_gelu(float x) {
   return x / (1.f + __expf(-1.702f * x));
 }

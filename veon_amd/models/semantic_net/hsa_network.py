@@ -1,0 +1,273 @@
+"""High-resolution side adaptor (HSA) network -- mirror of
+mmdet3d/models/semantic_net/side_adapter/highres_side_adaptor.py (SURVEY 8 row
+f3, the reference-owned half; the timm side-adapter ViT is third-party).
+
+It runs on the full-resolution image: 8x8 patches (11 264 tokens per camera at
+512x1408), three ``HighresSideAdaptorBlock`` s and the ``AttnManipulateBlock``
+that emits the dense attention biases for CLIP's tail blocks and the "supp"
+features for the lift's fusion layer.  Its cost is the eight 3x3 convolutions
+of the ``ConvBlock`` s (dim 384 on 64x176 maps: 179 GFLOP each, 1.4 TFLOP per
+6-camera sample -- more than the Conv3d body).
+
+Same class / parameter names as the reference; constructor arguments replace
+the detectron2 config (``HighresSideAdaptorNetwork.from_veon_config`` holds the
+values of configs/san_config.py:78-93).  With ``conv_dtype = torch.bfloat16`` (an
+opt-in, default ``None`` = the reference's fp32 PyTorch) the ConvBlocks run on
+the implicit-GEMM MFMA kernel in its 2-D mode with bias and GELU fused.
+Pinned by vectors from the reference file (oracle/tools/gen_golden_hsa.py).
+"""
+from typing import Dict, List
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ... import conv3d_ops, vit_ops
+
+
+class FeedForward(nn.Module):
+    def __init__(self, dim, hidden_dim, out_dim=-1):
+        super().__init__()
+        out_dim = dim if out_dim == -1 else out_dim
+        self.net = nn.Sequential(nn.LayerNorm(dim), nn.Linear(dim, hidden_dim), nn.GELU(),
+                                 nn.Linear(hidden_dim, out_dim))
+        self.conv_dtype = None   # set with the ConvBlocks (set_conv_dtype)
+
+    def train(self, mode=True):
+        self.__dict__.pop('_hip', None)
+        return super().train(mode)
+
+    def forward(self, x):
+        ln, fc1, _, fc2 = self.net
+        if (self.conv_dtype == torch.bfloat16 and x.is_cuda and not self.training
+                and not torch.is_grad_enabled() and fc1.in_features % 64 == 0
+                and fc1.out_features % 64 == 0 and fc2.out_features % 4 == 0
+                and x.dtype == torch.float32):
+            # LN -> GEMM(+bias, GELU) -> GEMM(+bias) on the MFMA kernels
+            if '_hip' not in self.__dict__:
+                self.__dict__['_hip'] = (
+                    vit_ops.to_bf16(fc1.weight.detach().float()),
+                    fc1.bias.detach().float().contiguous(),
+                    vit_ops.to_bf16(fc2.weight.detach().float()),
+                    fc2.bias.detach().float().contiguous())
+            w1, b1, w2, b2 = self.__dict__['_hip']
+            shp = x.shape
+            h = vit_ops.layernorm(x.contiguous().view(-1, shp[-1]), ln.weight.detach(),
+                                  ln.bias.detach(), ln.eps)
+            h = vit_ops.linear(h, w1, b1, vit_ops.EPI_GELU)
+            return vit_ops.linear(h, w2, b2).float().view(*shp[:-1], -1)
+        return self.net(x)
+
+
+class ConvBlock(nn.Module):
+    """tokens (B, L, dim) on an H x W map: conv3x3 -> GELU -> LN -> conv3x3 -> LN
+    (:31-52)."""
+
+    def __init__(self, dim, hidden_dim, out_dim=-1):
+        super().__init__()
+        out_dim = dim if out_dim == -1 else out_dim
+        self.conv1 = nn.Conv2d(dim, hidden_dim, stride=1, padding=1, kernel_size=3)
+        self.gelu = nn.GELU()
+        self.ln1 = nn.LayerNorm(hidden_dim)
+        self.conv2 = nn.Conv2d(hidden_dim, out_dim, stride=1, padding=1, kernel_size=3)
+        self.ln2 = nn.LayerNorm(out_dim)
+        self.dim, self.h_dim, self.out_dim = dim, hidden_dim, out_dim
+        self.conv_dtype = None
+
+    def train(self, mode=True):
+        self.__dict__.pop('_hip', None)
+        return super().train(mode)
+
+    def _hip_ok(self, x):
+        return (self.conv_dtype == torch.bfloat16 and x.is_cuda
+                and not torch.is_grad_enabled() and not self.training
+                and self.dim % 64 == 0 and self.h_dim % 64 == 0
+                and self.h_dim % 8 == 0 and self.out_dim % 8 == 0)
+
+    def _hip_forward(self, x, size):
+        B, L, _ = x.shape
+        H, W = size
+        st = self.__dict__.setdefault('_hip', {})
+        if 'w' not in st:
+            st['w'] = [(conv3d_ops.pack_weight2d(c.weight),
+                        c.bias.detach().float().contiguous())
+                       for c in (self.conv1, self.conv2)]
+            st['ln'] = [(ln.weight.detach().to(torch.bfloat16),
+                         ln.bias.detach().to(torch.bfloat16)) for ln in (self.ln1, self.ln2)]
+        key = (B, H, W)
+        if key not in st:
+            dev = x.device
+            st[key] = [conv3d_ops.PaddedImage(B, c, H, W, dev)
+                       for c in (self.dim, self.h_dim, self.h_dim, self.out_dim)]
+        a, b, c, d = st[key]
+        (w1, b1), (w2, b2) = st['w']
+        (g1, e1), (g2, e2) = st['ln']
+
+        def interior(img):
+            return img.rows.view(B, H + 2, W + 2, -1)[:, 1:-1, 1:-1]
+        # tokens are channels-last already: one strided copy into the interior
+        interior(a).copy_(x.view(B, H, W, self.dim))
+        conv3d_ops.conv2d_k3(a, w1, None, b1, act='gelu', out=b)
+        # LayerNorm over the channels of every pixel: bf16 in / out, fp32 inside
+        interior(c).copy_(F.layer_norm(interior(b), (self.h_dim,), g1, e1, self.ln1.eps))
+        conv3d_ops.conv2d_k3(c, w2, None, b2, out=d)
+        y = F.layer_norm(interior(d), (self.out_dim,), g2, e2, self.ln2.eps)
+        return y.float().reshape(B, L, self.out_dim)
+
+    def forward(self, x, size=(1, 1)):
+        B, L, dim = x.shape
+        H, W = size
+        assert H * W == L
+        if self._hip_ok(x):
+            return self._hip_forward(x, size)
+        x = x.permute(0, 2, 1).reshape(B, dim, H, W).contiguous()
+        x = self.gelu(self.conv1(x))
+        x = self.ln1(x.reshape(B, self.h_dim, L).permute(0, 2, 1))
+        x = x.permute(0, 2, 1).reshape(B, self.h_dim, H, W).contiguous()
+        x = self.conv2(x)
+        return self.ln2(x.reshape(B, self.out_dim, L).permute(0, 2, 1))
+
+
+class HighresSideAdaptorBlock(nn.Module):
+    """:108-135 -- x += ConvBlock(ln_3(x)); the last tokens += the (projected,
+    nearest-resized) CLIP feature map; ln_4."""
+
+    def __init__(self, dim, mlp_dim=960, neck_dim=0, pre_norm=False, use_add=False,
+                 use_checkpoint=False):
+        super().__init__()
+        self.ff = ConvBlock(dim, mlp_dim)
+        self.use_checkpoint = use_checkpoint
+        self.neck_add = nn.Linear(neck_dim, dim, bias=False) \
+            if neck_dim > 0 and use_add else nn.Identity()
+        self.use_add = use_add
+        self.pre_norm = nn.LayerNorm(dim) if pre_norm else nn.Identity()
+        self.ln_3 = nn.LayerNorm(dim)
+        self.ln_4 = nn.LayerNorm(dim)
+
+    def forward(self, x, x_pos, ext, ext_pos, offset=None, offset_shape=(1, 1)):
+        B, C_clip, h_ext, w_ext = ext.shape
+        x = self.pre_norm(x)
+        x = self.ff(self.ln_3(x), offset_shape) + x
+        if offset is not None:
+            offset = self.neck_add(offset.reshape(B, C_clip, -1).permute(0, 2, 1))
+            offset = F.interpolate(offset.permute(0, 2, 1).reshape(B, -1, h_ext, w_ext),
+                                   size=offset_shape)
+            offset = offset.reshape(B, offset.shape[1], -1).permute(0, 2, 1)
+            x = torch.cat([x[:, :-offset.shape[1]], x[:, -offset.shape[1]:] + offset], 1)
+        return self.ln_4(x)
+
+
+class AttnManipulateBlock(nn.Module):
+    """:138-193 -- ConvBlock, then two token-wise heads: per-layer / per-head
+    embeddings whose Gram matrices are CLIP's dense attention biases
+    (layers, B, heads, hw, hw), and the "supp" feature map for the lift."""
+
+    def __init__(self, dim, mlp_dim=768, clip_dim=1024, heads=16, dim_head=64,
+                 attn_layers=6, add_layers=2, supp_dim=384, pre_norm=False,
+                 use_checkpoint=False):
+        super().__init__()
+        self.use_checkpoint = use_checkpoint
+        self.pre_norm = nn.LayerNorm(dim) if pre_norm else nn.Identity()
+        self.ff = ConvBlock(dim, mlp_dim, mlp_dim)
+        self.dim, self.mlp_dim, self.clip_dim = dim, mlp_dim, clip_dim
+        self.add_layers, self.attn_layers = add_layers, attn_layers
+        self.heads, self.dim_head = heads, dim_head
+        self.attn_out = attn_layers * heads * dim_head
+        self.head_attn = FeedForward(mlp_dim, mlp_dim, self.attn_out)
+        self.head_supp = FeedForward(mlp_dim, mlp_dim, supp_dim)
+        self.ln_3 = nn.LayerNorm(dim)
+        self.ln_4 = nn.LayerNorm(mlp_dim)
+
+    def forward(self, x, side_shape=(1, 1), new_shape=(1, 1)):
+        x = self.pre_norm(x)
+        x = self.ln_4(self.ff(self.ln_3(x), side_shape))
+        attns = self.head_attn(x)
+        supp = self.head_supp(x)
+        H, W = side_shape
+        h, w = new_shape
+        B = x.shape[0]
+        attns = attns.permute(0, 2, 1).reshape(B, -1, H, W)
+        attns = F.interpolate(attns, size=(h, w), mode='bilinear').reshape(B, h, w, -1)
+        attns = attns.reshape(B, h * w, self.attn_layers, self.heads, self.dim_head)
+        attns = torch.einsum('bmahd,bnahd->bmnah', attns, attns).permute(3, 0, 4, 1, 2)
+        supp = supp.permute(0, 2, 1).reshape(B, -1, H, W)
+        return None, attns, supp
+
+
+class PatchEmbed(nn.Module):
+    """:196-229."""
+
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, embed_dim=768,
+                 norm_layer=True, flatten=True, bias=True):
+        super().__init__()
+        if isinstance(img_size, int):
+            img_size = (img_size, img_size)
+        if isinstance(patch_size, int):
+            patch_size = (patch_size, patch_size)
+        self.img_size, self.patch_size = img_size, patch_size
+        self.grid_size = (img_size[0] // patch_size[0], img_size[1] // patch_size[1])
+        self.num_patches = self.grid_size[0] * self.grid_size[1]
+        self.flatten = flatten
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size,
+                              stride=patch_size, bias=bias)
+        self.norm = nn.LayerNorm(embed_dim) if norm_layer else nn.Identity()
+
+    def forward(self, x):
+        x = self.proj(x)
+        _, c, h, w = x.shape
+        if self.flatten:
+            x = x.flatten(2).transpose(1, 2)
+        return self.norm(x), (h, w)
+
+
+class HighresSideAdaptorNetwork(nn.Module):
+    """:232-300.  ``cr_map``: layer -> (cross-attention source, add source) CLIP
+    layer indices (``FUSION_MAP`` strings 'i->j->k')."""
+
+    def __init__(self, patch_embed, hsa_net_body, rear_block, cr_map,
+                 use_checkpoint=False):
+        super().__init__()
+        self.patch_embed = patch_embed
+        self.hsa_net_body = hsa_net_body
+        self.rear_block = rear_block
+        self.cr_map = cr_map
+        self.use_checkpoint = use_checkpoint
+
+    @classmethod
+    def build(cls, dim=384, clip_dim=768, mlp_dim=384, input_size=(512, 1408),
+              patch_shape=(8, 8), num_heads=12, fusion_map=('0->3->3', '1->6->6', '2->9->9'),
+              manip_dim_head=32, manip_attn_layers=6, manip_add_layers=2,
+              manip_supp_dim=384):
+        """``from_config`` (:245-283) with explicit arguments; the defaults are
+        configs/san_config.py:78-93."""
+        cr_map = {int(i): (int(j), int(k)) for i, j, k in
+                  [x.split('->') for x in fusion_map]}
+        patch_embed = PatchEmbed(input_size, patch_shape, embed_dim=dim, norm_layer=False)
+        body = nn.ModuleList([
+            HighresSideAdaptorBlock(dim=dim, neck_dim=clip_dim, mlp_dim=mlp_dim,
+                                    pre_norm=(i == 0), use_add=cr_map[i][1] >= 0,
+                                    use_checkpoint=True)
+            for i in range(len(fusion_map))])
+        rear = AttnManipulateBlock(dim=dim, mlp_dim=mlp_dim, clip_dim=clip_dim,
+                                   heads=num_heads, dim_head=manip_dim_head,
+                                   attn_layers=manip_attn_layers,
+                                   add_layers=manip_add_layers, supp_dim=manip_supp_dim,
+                                   pre_norm=False, use_checkpoint=True)
+        return cls(patch_embed, body, rear, cr_map)
+
+    def set_conv_dtype(self, dtype):
+        """``torch.bfloat16``: ConvBlocks on the MFMA conv kernel at inference;
+        ``None``: the reference's fp32 PyTorch convolutions."""
+        for m in self.modules():
+            if isinstance(m, (ConvBlock, FeedForward)):
+                m.conv_dtype = dtype
+        return self
+
+    def forward(self, image, clip_features: Dict):
+        x, (H, W) = self.patch_embed(image)
+        h, w = clip_features[1].shape[2], clip_features[1].shape[3]
+        for layer_id, blk in enumerate(self.hsa_net_body):
+            ca_id, add_id = self.cr_map[layer_id]
+            x = blk(x, None, clip_features[ca_id].contiguous(), None,
+                    clip_features[add_id].contiguous() if blk.use_add else None, (H, W))
+        return self.rear_block(x, (H, W), (h, w))
