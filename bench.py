@@ -98,7 +98,7 @@ def bench_hotpath(args, rank, world, dev, dist):
     + heads, bf16, one 6-camera 256x704 sample per step (replicas for N > 1).
     The roofline object is the dominant MFMA kernel (the 3x3x3 conv body)."""
     from tools import hotpath_bench
-    r = hotpath_bench.run('vitb', head_bf16=True, dev=str(dev), iters=5, verbose=False)
+    r = hotpath_bench.run_full('vitb', (256, 704), dev=str(dev), iters=5, verbose=False)
     step = r['step']
     with torch.no_grad():
         for _ in range(args.warmup):
@@ -128,11 +128,14 @@ def bench_hotpath(args, rank, world, dev, dist):
         'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(ms, 4), 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
-        'config': {'workload': 'VEONB: 6-cam 256x704 -> DA-V2 ViT-B (MFMA encoder, DPT head '
-                               'bf16 with its 3x3 convs on the MFMA conv kernel) + CLIP ViT-B/16 trunk (MFMA) + sync-free '
-                               'lift (D=88, C=256, 200x200x16, fused 2x2x2 max-pool) + 4x '
-                               'ResBlock3D body + occ/sem heads + open-vocab classifier (MFMA) + upsampled '
-                               'outputs; random weights; SAN side adapter / HSA not included',
+        'config': {'workload': 'VEONB: the 3-D occupancy path of VeonTemporal.simple_test '
+                               '(veon_amd/models/veon_occ.py), 6-cam 256x704: DA-V2 ViT-B + DPT '
+                               'head -> depth; CLIP ViT-B/16 first 9 blocks -> HSA network -> '
+                               'CLIP tail with attention biases; CatFusionLift -> sync-free lift '
+                               '(D=88, C=256, 200x200x16, fused 2x2x2 max-pool) -> 4x ResBlock3D '
+                               '-> occ/sem heads -> open-vocab classifier -> upsample -> arg-max; '
+                               'bf16 on MFMA, random weights; timm side-adapter ViT / mask '
+                               'decoder / text encoder not included',
                    'parallelism': 'replicas x%d' % world,
                    'stages_ms': {k: round(v, 3) for k, v in r.items() if k.endswith('_ms')}},
         'roofline': {'kernel': 'k_conv3d_k3 (8 launches, AlignNetOcc3D body)', 'bound': 'mfma',

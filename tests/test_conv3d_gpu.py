@@ -402,3 +402,57 @@ def test_hsa_network_convblocks_on_mfma():
                           (attns, 'attns', 6e-2)):
         rel = ((got - t[key]).norm() / t[key].norm()).item()
         assert rel < tol, (key, rel)
+
+
+def test_veon_occupancy_path_harness_runs_and_is_stream_invariant():
+    """VeonOccupancyPath (depth model + CLIP trunk / HSA / tail + decoder +
+    classifier): shapes, finiteness, native kernels in use, and the two-stream
+    schedule gives the same result as the serial one."""
+    from veon_amd import synthetic
+    from veon_amd.models.veon_occ import VeonOccupancyPath
+    torch.manual_seed(0)
+    size, ncam = (64, 176), 2
+    net = VeonOccupancyPath(
+        input_size=size, num_cam=ncam, encoder='vitb', clip_width=64, clip_layers=4,
+        clip_heads=1, clip_first_tail=2, clip_proj_dim=64, embed_dim=64,
+        occ_size=(4, 20, 20), hsa_dim=64, hsa_fusion_map=('0->1->1', '1->2->2'),
+        grid_config={'x': [-10.0, 10.0, 1.0], 'y': [-10.0, 10.0, 1.0],
+                     'z': [-1.0, 3.0, 1.0], 'depth': [1.0, 13.0, 1.0]}).to(DEV).eval()
+    geom = [t.to(DEV) for t in synthetic.rig_inputs(synthetic.make_rig(1, ncam, size))]
+    images = torch.randn(1, ncam, 3, *size, device=DEV)
+    before = dict(_lib.CALLS)
+    with torch.no_grad():
+        a = net(images, geom)
+        net.two_streams = False
+        b = net(images, geom)
+    ran = {k for k, v in _lib.CALLS.items() if v > before.get(k, 0)}
+    assert {'veon_vit_block', 'veon_conv2d_k3_bf16', 'veon_conv3d_k3_bf16',
+            'veon_bev_pool_v2_fwd_maxpool_padded', 'veon_two_hot_depth'} <= ran, ran
+    assert a['sem_occ'].shape == (1, 17, 4, 20, 20) and a['bin_occ'].shape == (1, 2, 4, 20, 20)
+    assert a['occ_pred_cls'].shape == (1, 20, 20, 4)
+    for k in ('sem_occ', 'bin_occ'):
+        assert torch.isfinite(a[k]).all()
+        assert torch.equal(a[k], b[k]), k
+
+
+def test_cat_fusion_lift_mfma_path_feeds_the_lift_without_a_copy():
+    """CatFusionLift.hip_dtype = bf16: LN + 1x1 conv + ReLU as LayerNorm rows ->
+    GEMM, result channels-last bf16 handed over as an NCHW view -- exactly the
+    (B,N,H,W,C) half-precision feature rows the pool kernels gather."""
+    from veon_amd.models.semantic_net import CatFusionLift
+    torch.manual_seed(4)
+    fl = CatFusionLift(64, 128, 256).to(DEV).eval()
+    with torch.no_grad():
+        for ln in (fl.input_proj_1[0], fl.input_proj_2[0]):
+            ln.weight.uniform_(0.5, 1.5)
+            ln.bias.normal_(0, 0.2)
+    x1 = torch.randn(4, 64, 9, 13, device=DEV)
+    x2 = torch.randn(4, 128, 5, 7, device=DEV)
+    with torch.no_grad():
+        want = fl(x1, x2, (8, 11))
+        fl.hip_dtype = torch.bfloat16
+        got = fl(x1, x2, (8, 11))
+    assert got.dtype == torch.bfloat16 and got.shape == want.shape == (4, 256, 8, 11)
+    assert got.permute(0, 2, 3, 1).is_contiguous()
+    rel = ((got.float() - want).norm() / want.norm()).item()
+    assert rel < 1.5e-2, rel

@@ -18,6 +18,8 @@ throughput of the rows SURVEY section 8 puts on the hot path plus row f1, not a
 full VEON end-to-end number.
 
     python tools/hotpath_bench.py [vitb|vitl] [--head-bf16] [--veon-res] [--graph-clip]
+    python tools/hotpath_bench.py [vitb|vitl] --full [--veon-res]   (the real wiring:
+        veon_amd/models/veon_occ.py, incl. the HSA network and the CLIP tail)
 
 --veon-res: 512x1408 input as configs/veon/* (CLIP sees 705 tokens per camera,
 the lift 32x88 feature maps with D=88); default 256x704 as BASELINE.json.
@@ -53,6 +55,9 @@ def main():
     args = [a for a in sys.argv[1:] if not a.startswith('--')]
     enc = args[0] if args else 'vitb'
     size = (512, 1408) if '--veon-res' in sys.argv else (256, 704)
+    if '--full' in sys.argv:
+        run_full(enc, size)
+        return
     run(enc, '--head-bf16' in sys.argv, '--graph-clip' in sys.argv, size=size)
 
 
@@ -205,6 +210,47 @@ def run(enc='vitb', head_bf16=True, graph_clip=False, dev='cuda:0', iters=20,
                 body_ms=t_b, lift_body_heads_ms=t_lb, chained_one_stream_ms=t_ws,
                 chained_ms=t_w,
                 step=lambda: whole(img))
+
+
+def run_full(enc='vitb', size=(256, 704), dev='cuda:0', iters=20, verbose=True):
+    """The real wiring (veon_amd/models/veon_occ.py: FeatureExtractor -> HSA ->
+    CLIP tail with biases -> CatFusionLift -> lift -> body -> heads -> classifier)
+    instead of the stand-in projection of `run`; returns stage times (ms)."""
+    from veon_amd.models.veon_occ import VeonOccupancyPath
+
+    def say(*a):
+        if verbose:
+            print(*a, flush=True)
+    torch.manual_seed(0)
+    net = VeonOccupancyPath(input_size=size, encoder=enc).to(dev).eval()
+    geom = [t.to(dev) for t in synthetic.rig_inputs(synthetic.make_rig(1, 6, size))]
+    images = torch.randn(1, 6, 3, *size, device=dev)
+    img = images.flatten(0, 1)
+    with torch.no_grad():
+        out = net(images, geom)
+        torch.cuda.synchronize()
+        say('out', {k: tuple(v.shape) for k, v in out.items()})
+        t_d = timeit(lambda: net.estimate_depth(img), iters)
+        say('depth branch (DA-V2 encoder + DPT head) %.2f ms' % t_d)
+        t_s = timeit(lambda: net.clip_features(img), iters)
+        say('semantic branch (CLIP trunk + HSA network + CLIP tail with biases) %.2f ms' % t_s)
+        feats, supp = net.clip_features(img)
+        t_h = timeit(lambda: net.hsa(img, feats), iters)
+        say('  of which HSA network %.2f ms' % t_h)
+        dec = net.occ_decoder
+        vol = next(iter(dec.__dict__['_lifted'].values()))
+        t_b = timeit(lambda: dec.__dict__['_body'](vol, return_volume=True), iters)
+        say('Conv3d body alone %.3f ms' % t_b)
+        net.two_streams = False
+        t_1 = timeit(lambda: net(images, geom), iters)
+        say('whole path, one stream %.2f ms' % t_1)
+        net.two_streams = True
+        t_2 = timeit(lambda: net(images, geom), iters)
+        say('whole path, encoder branches on two streams %.2f ms -> %.1f 6-cam samples/s'
+            % (t_2, 1e3 / t_2))
+    return dict(depth_branch_ms=t_d, semantic_branch_ms=t_s, hsa_ms=t_h, body_ms=t_b,
+                decoder_ms=t_1 - t_d - t_s, chained_one_stream_ms=t_1, chained_ms=t_2,
+                step=lambda: net(images, geom))
 
 
 if __name__ == '__main__':

@@ -25,6 +25,14 @@ import torch.nn.functional as F
 from ... import conv3d_ops, vit_ops
 
 
+def _interp(x, **kw):
+    """F.interpolate; on a GPU in channels-last (same values, and torch's NCHW
+    kernels are very slow for many-channel, small maps)."""
+    if x.is_cuda:
+        x = x.contiguous(memory_format=torch.channels_last)
+    return F.interpolate(x, **kw)
+
+
 class FeedForward(nn.Module):
     def __init__(self, dim, hidden_dim, out_dim=-1):
         super().__init__()
@@ -150,8 +158,8 @@ class HighresSideAdaptorBlock(nn.Module):
         x = self.ff(self.ln_3(x), offset_shape) + x
         if offset is not None:
             offset = self.neck_add(offset.reshape(B, C_clip, -1).permute(0, 2, 1))
-            offset = F.interpolate(offset.permute(0, 2, 1).reshape(B, -1, h_ext, w_ext),
-                                   size=offset_shape)
+            offset = _interp(offset.permute(0, 2, 1).reshape(B, -1, h_ext, w_ext),
+                             size=offset_shape)
             offset = offset.reshape(B, offset.shape[1], -1).permute(0, 2, 1)
             x = torch.cat([x[:, :-offset.shape[1]], x[:, -offset.shape[1]:] + offset], 1)
         return self.ln_4(x)
@@ -187,7 +195,10 @@ class AttnManipulateBlock(nn.Module):
         h, w = new_shape
         B = x.shape[0]
         attns = attns.permute(0, 2, 1).reshape(B, -1, H, W)
-        attns = F.interpolate(attns, size=(h, w), mode='bilinear').reshape(B, h, w, -1)
+        # (the reference reshapes the NCHW result to (B, h, w, -1) without a
+        # permute -- kept as is, :177-178)
+        attns = _interp(attns, size=(h, w), mode='bilinear').contiguous() \
+            .reshape(B, h, w, -1)
         attns = attns.reshape(B, h * w, self.attn_layers, self.heads, self.dim_head)
         attns = torch.einsum('bmahd,bnahd->bmnah', attns, attns).permute(3, 0, 4, 1, 2)
         supp = supp.permute(0, 2, 1).reshape(B, -1, H, W)

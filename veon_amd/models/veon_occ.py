@@ -1,0 +1,151 @@
+"""The 3-D occupancy path of ``VeonTemporal.simple_test`` assembled from this
+package's mirrors (single frame, inference):
+
+    images (B, N, 3, H, W) + calibration
+      depth    : DepthAnythingV2Adaptor at 252x700 -> metric depth at (H/2, W/2)
+                 (veon_temporal.py:209-214)
+      semantic : CLIP trunk on the half-resolution image, first K blocks
+                 (FeatureExtractor) -> HSA network on the full image (attention
+                 biases + supp features) -> CLIP tail blocks with the biases
+                 (RecWithAttnbiasHead.update_remaining_clip_feats)
+                 (san_in_veon_temporal.py:118-123, 189-191)
+      3-D      : AlignNetOcc3D (fusion layer -> lift -> Conv3d body -> heads),
+                 open-vocabulary classifier, trilinear upsampling, arg-max
+                 (san_in_veon_temporal.py:193-211, veon_temporal.py:216-227)
+
+NOT included (third-party / not rebuilt): the timm side-adapter ViT, its mask
+decoder and the 2-D segmentation outputs (``sem_embed_ds`` only supplies a shape
+to the decoder), the text encoder (class embeddings are an input), the temporal
+path.  Weights are whatever the sub-modules hold (random unless loaded).
+
+The two encoder branches are independent and neither fills the chip, so they run
+on two HIP streams (``two_streams=True``).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .builder import build_neck
+from .semantic_net import (AlignNetOcc3D, ClipRecHead, ClipVisualTrunk,
+                           semantic_inference_3d_fused)
+from .semantic_net.hsa_network import HighresSideAdaptorNetwork
+
+
+class VeonOccupancyPath(nn.Module):
+    def __init__(self, input_size=(256, 704), grid_config=None, num_cam=6,
+                 encoder='vitb', n_classes=17, clip_width=768, clip_layers=12,
+                 clip_heads=12, clip_first_tail=9, clip_proj_dim=512, embed_dim=256,
+                 occ_size=(16, 200, 200), bf16_heads=True, two_streams=True,
+                 hsa_dim=384, hsa_fusion_map=('0->3->3', '1->6->6', '2->9->9')):
+        super().__init__()
+        from .. import synthetic
+        grid_config = grid_config or synthetic.GRID_VEON
+        dav2_cfg = {'vitb': dict(encoder='vitb', features=128,
+                                 out_channels=[96, 192, 384, 768]),
+                    'vitl': dict(encoder='vitl', features=256,
+                                 out_channels=[256, 512, 1024, 1024])}[encoder]
+        self.depth_model = build_neck(dict(type='DepthAnythingV2Adaptor', max_depth=80.0,
+                                           use_lora=True, lora_r=16, **dav2_cfg))
+        self.clip_trunk = ClipVisualTrunk(224, 16, clip_width, clip_layers, clip_heads)
+        self.clip_first_tail = clip_first_tail
+        self.ln_post = nn.LayerNorm(clip_width)
+        self.clip_proj = nn.Parameter(torch.randn(clip_width, clip_proj_dim)
+                                      * clip_width ** -0.5)
+        self.clip_rec_head = ClipRecHead(self.clip_trunk.resblocks, self.ln_post,
+                                         self.clip_proj, first_layer_idx=clip_first_tail)
+        self.hsa = HighresSideAdaptorNetwork.build(
+            dim=hsa_dim, clip_dim=clip_width, mlp_dim=hsa_dim, input_size=input_size,
+            fusion_map=hsa_fusion_map, manip_supp_dim=hsa_dim, num_heads=clip_heads,
+            manip_attn_layers=max(clip_layers - clip_first_tail, 1))
+        self.view_transformer = build_neck(dict(
+            type='LSSViewTransformerRaw', grid_config=grid_config, input_size=input_size,
+            out_channels=embed_dim, collapse_z=False, ds_feat=[2, 2, 2]))
+        self.view_transformer.sync_free = True
+        self.occ_decoder = AlignNetOcc3D(
+            clip_dim=clip_width, hsa_dim=hsa_dim, embed_dim=embed_dim,
+            clip_outdim=clip_proj_dim, layer_lifting_map=['%d->0->0' % clip_layers],
+            fusion_type='cat_fusion', layer_depth=4)
+        self.occ_decoder.lss_view_transformer = self.view_transformer
+        self.occ_decoder.num_frame, self.occ_decoder.num_camera = 1, num_cam
+        self.ov_classifier_weight = nn.Parameter(torch.randn(n_classes, clip_proj_dim))
+        self.input_size, self.num_cam, self.occ_size = input_size, num_cam, occ_size
+        self.two_streams = two_streams
+        if bf16_heads:
+            self.depth_model.head_dtype = torch.bfloat16
+            self.hsa.set_conv_dtype(torch.bfloat16)
+            for layer in self.occ_decoder.fusion_layers.values():
+                layer.hip_dtype = torch.bfloat16
+        self.__dict__['_side'] = None
+
+    # ------------------------------------------------------------- branches
+    def estimate_depth(self, img):
+        """(B*N,3,H,W) -> metric depth (B, N, H/2, W/2) (veon_temporal.py:209-214;
+        the reference resizes to 252x700 for any of its input sizes)."""
+        H, W = img.shape[-2:]
+        x = F.interpolate(img, (252, 700), mode='bilinear', align_corners=False)
+        d = self.depth_model(x)['metric_depth']
+        d = F.interpolate(d[:, None], (H // 2, W // 2), mode='bilinear',
+                          align_corners=True)[:, 0]
+        return d.view(-1, self.num_cam, H // 2, W // 2)
+
+    def clip_features(self, img):
+        """FeatureExtractor on the half-resolution image, HSA on the full one,
+        then the CLIP tail with the HSA attention biases -> the reference's
+        ``ClipOutput`` dict (+ 'supp')."""
+        x = F.interpolate(img, scale_factor=0.5, mode='bilinear', align_corners=False)
+        outs, hw = self.clip_trunk(x, last_layer_idx=self.clip_first_tail)
+        feats = {}
+        for i, t in enumerate(outs):
+            ClipRecHead._save(feats, i, t, hw)
+        _, attns, supp = self.hsa(img, feats)
+        feats = self.clip_rec_head.update_remaining_clip_feats(feats, None, attns)
+        return feats, supp
+
+    def forward(self, images, img_metas):
+        """images (B, N, 3, H, W); img_metas = (sensor2egos, ego2globals, intrins,
+        post_rots, post_trans, bda) as the reference's ``img[1:7]``.  Returns
+        ``bin_occ`` / ``sem_occ`` at ``occ_size`` and ``occ_pred_cls``."""
+        B, N = images.shape[:2]
+        img = images.flatten(0, 1)
+        if self.two_streams and img.is_cuda:
+            if self.__dict__['_side'] is None:
+                self.__dict__['_side'] = torch.cuda.Stream()
+            side, cur = self.__dict__['_side'], torch.cuda.current_stream()
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                feats, supp = self.clip_features(img)
+            depth = self.estimate_depth(img)
+            cur.wait_stream(side)
+            for t in list(feats.values()) + [supp]:
+                t.record_stream(cur)
+        else:
+            feats, supp = self.clip_features(img)
+            depth = self.estimate_depth(img)
+        hf, wf = self.input_size[0] // 16, self.input_size[1] // 16
+        sem_embed_ds = images.new_zeros((B * N, 1, hf, wf))   # shape carrier only
+        metas = list(img_metas[:5]) + [img_metas[5][None]]
+        dec = self.occ_decoder
+        fast = (dec._fast_path(sem_embed_ds)
+                and self.view_transformer._can_fuse_ds(sem_embed_ds))
+        if fast:   # keep the sem head's output as a padded volume for the classifier
+            depth2 = dec.prepare_depth(depth)
+            metas2 = dec.prepare_meta(metas)
+            vol = dec._lift_volume(depth2.shape[0], dec.layers_3d_body[0].conv1.conv.in_channels,
+                                   img.device)
+            x = dec.fuse(0, None, feats, [supp], depth2, metas2, None, (hf, wf),
+                         out_volume=vol)
+            x = dec.__dict__['_body'](x, return_volume=True)
+            bin_occ = dec.occupancy_pred(x)
+            feat = dec.feat_pred(x, return_volume=True)
+        else:
+            out = dec(sem_embed_ds, feats, [supp], depth, metas)
+            bin_occ, feat = out['bin_occ'], out['feat_occ']
+        sem_occ = semantic_inference_3d_fused(self.ov_classifier_weight, feat, self.occ_size)
+        bin_occ = F.interpolate(bin_occ, size=tuple(self.occ_size), mode='trilinear',
+                                align_corners=False)
+        # veon_temporal.py:219-227
+        score, cls = torch.softmax(sem_occ, dim=1).max(dim=1)
+        keep = (score > 0.0) & (torch.softmax(bin_occ, dim=1)[:, 0] > 0.5)
+        occ = torch.where(keep, cls, torch.full_like(cls, sem_occ.shape[1]))
+        return {'bin_occ': bin_occ, 'sem_occ': sem_occ,
+                'occ_pred_cls': occ.permute(0, 3, 2, 1).contiguous()}
