@@ -374,6 +374,30 @@ int veon_image_resize_bilinear(const void *in_padded, void *out_padded, int B,
  * act 0 none / 1 ReLU / 2 sigmoid (the tail of DPTHead.output_conv2, dpt.py). */
 int veon_image_dot(const void *in_padded, const float *w, float bias, float *out,
                    int B, int C, int Y, int X, int act, void *stream);
+/* ---- temporal path, csrc/temporal.hip ---------------------
+ * Sampling + attention core of TemporalDeformable.forward
+ * (mmdet3d/models/semantic_net/side_adapter/align_net_occ3d.py:138-196), replacing
+ * its repeat + F.grid_sample + two einsums + softmax.  All operands are padded
+ * channels-last bf16 grids of one (B,Z,Y,X) shape: kv has 2*C channels laid out
+ * per head as [key hd | value hd] (the reference's view of key_value_proj), q has
+ * C, off has off_channels >= heads*samples*3 raw (pre-tanh) offsets ordered
+ * (head, sample, axis); out (C channels) gets its interior rows written, the
+ * halo is not touched.  samples must be 8; C/heads in {32, 64}. */
+int veon_deform_attention_bf16(const void *kv_padded, const void *q_padded,
+                               const void *off_padded, void *out_padded, int B,
+                               int Z, int Y, int X, int C, int heads, int samples,
+                               int off_channels, void *stream);
+/* SANInVeonTemporal.align_after_lss (san_in_veon_temporal.py:325-365) on a padded
+ * grid: out voxel (x,y,z) = trilinear sample of `in` at affine[b] (3x4 row-major,
+ * voxel-index units) applied to (x,y,z,1); zero outside (F.grid_sample
+ * padding_mode='zeros', align_corners=True). */
+int veon_volume_warp_bf16(const void *in_padded, void *out_padded,
+                          const float *affine, int B, int C, int Z, int Y, int X,
+                          void *stream);
+/* zero the halo rows of a padded grid (after a row-wise GEMM epilogue wrote its
+ * shift there and a 3x3x3 conv is to consume it). */
+int veon_volume_zero_halo_bf16(void *padded, int B, int C, int Z, int Y, int X,
+                               void *stream);
 /* (B,C,Z,Y,X) fp32 <-> interior of the padded channels-last bf16 grid (the halo
  * is not touched: allocate the grid zeroed once). */
 int veon_volume_pack_bf16(const float *ncdhw, void *padded, int B, int C, int Z,

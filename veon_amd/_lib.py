@@ -65,6 +65,9 @@ _SIGNATURES = {
     'veon_image_dot': (_ci, [_vp, _vp, _cf, _vp] + [_ci] * 5 + [_vp]),
     'veon_image_pack_bf16': (_ci, [_vp, _ci, _vp] + [_ci] * 4 + [_vp]),
     'veon_image_unpack': (_ci, [_vp, _vp, _ci] + [_ci] * 4 + [_vp]),
+    'veon_deform_attention_bf16': (_ci, [_vp] * 4 + [_ci] * 8 + [_vp]),
+    'veon_volume_warp_bf16': (_ci, [_vp] * 3 + [_ci] * 5 + [_vp]),
+    'veon_volume_zero_halo_bf16': (_ci, [_vp] + [_ci] * 5 + [_vp]),
     'veon_volume_pack_bf16': (_ci, [_vp, _vp] + [_ci] * 5 + [_vp]),
     'veon_volume_unpack_f32': (_ci, [_vp, _vp] + [_ci] * 5 + [_vp]),
     'veon_camera_matrices': (_ci, [_ci] + [_vp] * 6 + [_vp]),

@@ -73,9 +73,10 @@ def pack_weight(w):
 
 
 def conv3d_k3(vol, w_packed, scale=None, shift=None, resid=None, relu=False,
-              out=None):
+              out=None, act=None):
     """3x3x3 stride-1 pad-1 convolution on a PaddedVolume with the fused
-    epilogue ``relu?(conv*scale + shift + resid?)`` -> PaddedVolume."""
+    epilogue ``act(conv*scale + shift + resid?)`` -> PaddedVolume; ``act`` in
+    none / relu / gelu (``relu=True`` is shorthand for act='relu')."""
     dev = _lib.require_device(vol.storage, w_packed)
     B, Cin, Z, Y, X = vol.shape
     Cout = w_packed.shape[0]
@@ -90,10 +91,58 @@ def conv3d_k3(vol, w_packed, scale=None, shift=None, resid=None, relu=False,
         st = _lib.lib().veon_conv3d_k3_bf16(
             _lib.ptr(vol.rows), _lib.ptr(w_packed), _lib.ptr(scale),
             _lib.ptr(shift), _lib.ptr(None if resid is None else resid.rows),
-            _lib.ptr(out.rows), B, Z, Y, X, Cin, Cout, 1 if relu else 0,
+            _lib.ptr(out.rows), B, Z, Y, X, Cin, Cout, 1 if relu else _ACT[act],
             _lib.stream_ptr(dev))
     _lib.check(st, 'veon_conv3d_k3_bf16')
     return out
+
+
+def deform_attention(kv, q, off, heads, samples=8, out=None):
+    """Sampling + attention core of TemporalDeformable on PaddedVolumes: ``kv``
+    (2C channels, per head [key | value]), ``q`` (C), ``off`` (>= heads*samples*3
+    raw offsets; tanh is applied here) -> PaddedVolume (C), halo zero."""
+    dev = _lib.require_device(kv.storage, q.storage, off.storage)
+    B, C, Z, Y, X = q.shape
+    assert kv.shape == (B, 2 * C, Z, Y, X) and off.shape[0] == B
+    assert tuple(off.shape[2:]) == (Z, Y, X)
+    if out is None:
+        out = q.like()
+    assert out.shape == q.shape and out is not q
+    with torch.cuda.device(dev):
+        st = _lib.lib().veon_deform_attention_bf16(
+            _lib.ptr(kv.rows), _lib.ptr(q.rows), _lib.ptr(off.rows), _lib.ptr(out.rows),
+            B, Z, Y, X, C, heads, samples, off.shape[1], _lib.stream_ptr(dev))
+    _lib.check(st, 'veon_deform_attention_bf16')
+    return out
+
+
+def warp_volume(vol, affine, out=None):
+    """Trilinear resampling of a PaddedVolume at ``affine`` (B,3,4 fp32, voxel
+    index units) applied to each output voxel index; zeros outside."""
+    dev = _lib.require_device(vol.storage)
+    B, C, Z, Y, X = vol.shape
+    affine = affine.to(device=dev, dtype=torch.float32).contiguous()
+    assert tuple(affine.shape) == (B, 3, 4)
+    if out is None:
+        out = vol.like()
+    assert out.shape == vol.shape and out is not vol
+    with torch.cuda.device(dev):
+        st = _lib.lib().veon_volume_warp_bf16(
+            _lib.ptr(vol.rows), _lib.ptr(out.rows), _lib.ptr(affine), B, C, Z, Y, X,
+            _lib.stream_ptr(dev))
+    _lib.check(st, 'veon_volume_warp_bf16')
+    return out
+
+
+def zero_halo(vol):
+    """Reset the halo rows of a PaddedVolume to zero, in place."""
+    dev = _lib.require_device(vol.storage)
+    B, C, Z, Y, X = vol.shape
+    with torch.cuda.device(dev):
+        st = _lib.lib().veon_volume_zero_halo_bf16(_lib.ptr(vol.rows), B, C, Z, Y, X,
+                                                   _lib.stream_ptr(dev))
+    _lib.check(st, 'veon_volume_zero_halo_bf16')
+    return vol
 
 
 # ----------------------------------------------------------------- 2-D images
