@@ -394,6 +394,14 @@ int veon_deform_attention_bf16(const void *kv_padded, const void *q_padded,
 int veon_volume_warp_bf16(const void *in_padded, void *out_padded,
                           const float *affine, int B, int C, int Z, int Y, int X,
                           void *stream);
+/* The coordinate chain of align_after_lss (san_in_veon_temporal.py:326-358) as one
+ * 3x4 map in voxel-index units per sample, computed on the device in double:
+ * affine[b] = S^-1 inv(prev2glob[b]) cur2glob[b] S, S = diag(step) + first voxel
+ * centre.  cur2glob / prev2glob: device fp32 4x4 row-major, mat_stride floats
+ * apart (>= 16); first_xyz / step_xyz: HOST doubles[3]; affine: device (B,3,4). */
+int veon_warp_affine(const float *cur2glob, const float *prev2glob, int mat_stride,
+                     const double *first_xyz, const double *step_xyz, float *affine,
+                     int B, void *stream);
 /* zero the halo rows of a padded grid (after a row-wise GEMM epilogue wrote its
  * shift there and a 3x3x3 conv is to consume it). */
 int veon_volume_zero_halo_bf16(void *padded, int B, int C, int Z, int Y, int X,

@@ -101,6 +101,35 @@ def main():
     print('wrote', path, {k: tuple(v.shape) for k, v in out.items()}, tuple(early.shape),
           float(early.abs().sum()))
 
+    # ---- temporal decoder (num_temporal=2): forward_early of a past frame, then
+    # forward(..., occ_feat_prevs) -- align_net_occ3d.py:252-262, 268-280 ----------
+    net_t = ao.AlignNetOcc3D(clip_dim=32, hsa_dim=16, embed_dim=32, clip_outdim=24,
+                             layer_lifting_map=['2->0->0'], fusion_type='cat_fusion',
+                             layer_depth=1, num_temporal=2).eval()
+    randomise(net_t, gen)
+    with torch.no_grad():
+        net_t.temporal_fusion.deform_fusion_layer.t_deform.offset_conv[2].weight.mul_(6.0)
+    vt_t = raw.LSSViewTransformerRaw(grid_config=GRID, input_size=SIZE, downsample=16,
+                                     out_channels=32, collapse_z=False, ds_feat=[2, 2, 2])
+    net_t.lss_view_transformer = vt_t
+    net_t.num_frame, net_t.num_camera = 1, N
+    metric_prev = torch.rand(1, N, hf * 8, wf * 8, generator=gen) * 14
+    clip2_prev = torch.randn(N, 32, 3, 7, generator=gen)
+    supp_prev = torch.randn(N, 16, 6, 14, generator=gen)
+    with torch.no_grad():
+        early_prev = net_t.forward_early(sem_feat, {1: clip1, 2: clip2_prev}, [supp_prev],
+                                         metric_prev, metas)
+        out_t = net_t(sem_feat, {1: clip1, 2: clip2}, [supp], metric, metas, [early_prev])
+    res_t = {'metric_prev': metric_prev, 'clip2_prev': clip2_prev, 'supp_prev': supp_prev,
+             'early_prev': early_prev, 'bin_occ': out_t['bin_occ'],
+             'feat_occ': out_t['feat_occ']}
+    res_t.update({'sd/' + k: v for k, v in net_t.state_dict().items()
+                  if 'lss_view_transformer' not in k})
+    path = os.path.join(ROOT, 'tests', 'golden', 'align_net_temporal_tiny.npz')
+    np.savez_compressed(path, **{k: v.detach().numpy() for k, v in res_t.items()})
+    print('wrote', path, {k: tuple(v.shape) for k, v in out_t.items()},
+          float(early_prev.abs().sum()))
+
 
 if __name__ == '__main__':
     main()

@@ -123,3 +123,84 @@ def test_temporal_fusion_mfma_path_matches_module(T):
     err = (got - want).abs()
     assert err.max().item() <= 0.12 * rms and err.pow(2).mean().sqrt().item() <= 0.03 * rms, \
         (err.max().item(), err.pow(2).mean().sqrt().item(), rms)
+
+
+def _decoder(embed, depth_layers, sd=None):
+    from veon_amd.models import build_neck
+    from veon_amd.models.semantic_net import AlignNetOcc3D
+    net = AlignNetOcc3D(clip_dim=32, hsa_dim=16, embed_dim=embed, clip_outdim=24,
+                        layer_lifting_map=['2->0->0'], fusion_type='cat_fusion',
+                        layer_depth=depth_layers, num_temporal=2)
+    if sd is not None:
+        net.load_state_dict(sd, strict=True)
+    grid = {'x': [-10.0, 10.0, 1.0], 'y': [-10.0, 10.0, 1.0], 'z': [-1.0, 3.0, 1.0],
+            'depth': [1.0, 13.0, 1.0]}
+    net.lss_view_transformer = build_neck(dict(
+        type='LSSViewTransformerRaw', grid_config=grid, input_size=(64, 176),
+        downsample=16, out_channels=embed, collapse_z=False, ds_feat=[2, 2, 2]))
+    net.num_frame, net.num_camera = 1, 2
+    return net.to(DEV).eval()
+
+
+def test_temporal_decoder_matches_reference_vectors():
+    """AlignNetOcc3D(num_temporal=2): forward_early of a past frame, then
+    forward(..., occ_feat_prevs) against the reference's own decoder run on CPU
+    (oracle/tools/gen_golden_align_net.py, second half).  embed_dim 32: the fp32
+    module definitions run around the HIP lift."""
+    from tests.conftest import load_golden
+    t = {k: torch.from_numpy(v).to(DEV) for k, v in load_golden('align_net_tiny').items()}
+    tt = {k: torch.from_numpy(v).to(DEV)
+          for k, v in load_golden('align_net_temporal_tiny').items()}
+    net = _decoder(32, 1, {k[3:]: v for k, v in tt.items() if k.startswith('sd/')})
+    metas = [t['s2e'], t['e2g'], t['intr'], t['pr'], t['pt'], t['bda'][None]]
+    sem_feat = torch.zeros(2, 8, 4, 11, device=DEV)
+    with torch.no_grad():
+        early = net.forward_early(sem_feat, {1: t['clip1'], 2: tt['clip2_prev']},
+                                  [tt['supp_prev']], tt['metric_prev'], metas)
+        torch.testing.assert_close(early, tt['early_prev'], rtol=1e-4, atol=1e-4)
+        out = net(sem_feat, {1: t['clip1'], 2: t['clip2']}, [t['supp']], t['metric'],
+                  metas, [early])
+    for key in ('bin_occ', 'feat_occ'):
+        rel = ((out[key] - tt[key]).norm() / tt[key].norm()).item()
+        assert rel < 1e-3, (key, rel)
+
+
+def test_temporal_decoder_fast_path_agrees_with_modules():
+    """embed_dim 256: past frame lifted straight into a PaddedVolume, warped on the
+    grid, fused and decoded on the MFMA path -- against the same decoder with the
+    native paths switched off (fp32 modules around the HIP lift)."""
+    from tests.conftest import load_golden
+    from veon_amd import _lib
+    t = {k: torch.from_numpy(v).to(DEV) for k, v in load_golden('align_net_tiny').items()}
+    torch.manual_seed(5)
+    net = _decoder(256, 1)
+    gen = torch.Generator().manual_seed(5)
+    _randomise(net.cpu(), gen)
+    net = net.to(DEV)
+    metas = [t['s2e'], t['e2g'], t['intr'], t['pr'], t['pt'], t['bda'][None]]
+    clip = {1: t['clip1'], 2: t['clip2']}
+    sem_feat = torch.zeros(2, 8, 4, 11, device=DEV)
+    grid = net.lss_view_transformer.grid_config
+    eye = torch.eye(4, device=DEV)[None, None]
+    move = eye.clone()
+    move[0, 0, :3, 3] = torch.tensor([1.3, -0.6, 0.2])
+    with torch.no_grad():
+        vol = conv3d_ops.PaddedVolume(1, 256, 2, 10, 10, DEV)
+        before = dict(_lib.CALLS)
+        early = net.forward_early(sem_feat, clip, [t['supp'] * 0.5], t['metric'], metas,
+                                  out_volume=vol)
+        assert early is vol
+        prev = tfm.align_after_lss(early, [eye, move], grid, (2, 2, 2))
+        fast = net(sem_feat, clip, [t['supp']], t['metric'], metas, [prev])
+        ran = {k for k, v in _lib.CALLS.items() if v > before.get(k, 0)}
+        assert {'veon_volume_warp_bf16', 'veon_deform_attention_bf16',
+                'veon_conv3d_k3_bf16', 'veon_bev_pool_v2_fwd_maxpool_padded'} <= ran, ran
+        net.use_hip = False
+        for m in (net.occupancy_pred, net.feat_pred):
+            m._hip_ok = lambda x: False
+        early32 = net.forward_early(sem_feat, clip, [t['supp'] * 0.5], t['metric'], metas)
+        prev32 = tfm.align_after_lss(early32, [eye, move], grid, (2, 2, 2))
+        slow = net(sem_feat, clip, [t['supp']], t['metric'], metas, [prev32])
+    for key in ('bin_occ', 'feat_occ'):
+        rel = ((fast[key] - slow[key]).norm() / slow[key].norm()).item()
+        assert rel < 4e-2, (key, rel)

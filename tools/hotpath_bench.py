@@ -55,6 +55,10 @@ def main():
     args = [a for a in sys.argv[1:] if not a.startswith('--')]
     enc = args[0] if args else 'vitb'
     size = (512, 1408) if '--veon-res' in sys.argv else (256, 704)
+    for a in sys.argv:
+        if a.startswith('--temporal'):
+            run_temporal(enc, size, T=int(a.split('=')[1]) if '=' in a else 1)
+            return
     if '--full' in sys.argv:
         run_full(enc, size)
         return
@@ -251,6 +255,48 @@ def run_full(enc='vitb', size=(256, 704), dev='cuda:0', iters=20, verbose=True):
     return dict(depth_branch_ms=t_d, semantic_branch_ms=t_s, hsa_ms=t_h, body_ms=t_b,
                 decoder_ms=t_1 - t_d - t_s, chained_one_stream_ms=t_1, chained_ms=t_2,
                 step=lambda: net(images, geom))
+
+
+def run_temporal(enc='vitb', size=(256, 704), T=1, dev='cuda:0', iters=10):
+    """The occupancy path with T past frames: (a) as the
+    reference runs it -- every step recomputes the past frames' encoders and lift
+    (san_in_veon_temporal.py:158-173) -- and (b) streaming: the past frames'
+    lifted volumes are kept from their own steps, only warp + fusion are added."""
+    from veon_amd.models.veon_occ import VeonOccupancyPath
+    torch.manual_seed(0)
+    net = VeonOccupancyPath(input_size=size, encoder=enc, num_temporal=T + 1).to(dev).eval()
+    geom = [t.to(dev) for t in synthetic.rig_inputs(synthetic.make_rig(1, 6, size))]
+    frames = [torch.randn(1, 6, 3, *size, device=dev) for _ in range(T + 1)]
+    eye = torch.eye(4, device=dev)[None, None]
+    adj = []
+    for k in range(T):
+        m = eye.clone()
+        m[0, 0, :3, 3] = torch.tensor([1.5 * (k + 1), 0.2, 0.01])
+        adj.append([eye, m])
+    with torch.no_grad():
+        kept = [net.lift_frame(frames[1 + k], geom) for k in range(T)]
+
+        def as_reference():
+            prevs = [net.align(net.lift_frame(frames[1 + k], geom, out_volume=kept[k]), adj[k])
+                     for k in range(T)]
+            return net(frames[0], geom, prevs)
+
+        def streaming():
+            return net(frames[0], geom, [net.align(kept[k], adj[k]) for k in range(T)])
+        out = as_reference()
+        torch.cuda.synchronize()
+        print('out', {k: tuple(v.shape) for k, v in out.items()}, flush=True)
+        t_single = timeit(lambda: net(frames[0], geom), iters)
+        t_ref = timeit(as_reference, iters)
+        t_str = timeit(streaming, iters)
+        t_lift = timeit(lambda: net.lift_frame(frames[1], geom, out_volume=kept[0]), iters)
+    print('%s %dx%d, T=%d past frames: single frame %.2f ms | past frame encoders + lift '
+          '%.2f ms each | recomputing the past every step (as the reference) %.2f ms -> '
+          '%.1f samples/s | streaming (kept volumes: warp + temporal fusion only) %.2f ms '
+          '-> %.1f samples/s' % (enc, size[0], size[1], T, t_single, t_lift, t_ref,
+                                  1e3 / t_ref, t_str, 1e3 / t_str), flush=True)
+    return dict(single_ms=t_single, lift_frame_ms=t_lift, reference_order_ms=t_ref,
+                streaming_ms=t_str)
 
 
 if __name__ == '__main__':

@@ -134,6 +134,30 @@ def warp_volume(vol, affine, out=None):
     return out
 
 
+def warp_affine(cur2glob, prev2glob, first_xyz, step_xyz):
+    """(B,1,4,4) or (B,4,4) ROCm fp32 ego->global transforms of the current and a
+    past frame -> (B,3,4) voxel-index map for ``warp_volume`` (no host sync)."""
+    import ctypes
+    dev = _lib.require_device(cur2glob, prev2glob)
+    mats = []
+    for m in (cur2glob, prev2glob):
+        m = m.float()
+        if m.dim() == 4:
+            m = m[:, 0]
+        mats.append(m.contiguous())
+    B = mats[0].shape[0]
+    assert tuple(mats[0].shape) == tuple(mats[1].shape) == (B, 4, 4)
+    out = torch.empty((B, 3, 4), dtype=torch.float32, device=dev)
+    first = (ctypes.c_double * 3)(*[float(v) for v in first_xyz])
+    step = (ctypes.c_double * 3)(*[float(v) for v in step_xyz])
+    with torch.cuda.device(dev):
+        st = _lib.lib().veon_warp_affine(_lib.ptr(mats[0]), _lib.ptr(mats[1]), 16,
+                                         first, step, _lib.ptr(out), B,
+                                         _lib.stream_ptr(dev))
+    _lib.check(st, 'veon_warp_affine')
+    return out
+
+
 def zero_halo(vol):
     """Reset the halo rows of a PaddedVolume to zero, in place."""
     dev = _lib.require_device(vol.storage)

@@ -170,6 +170,57 @@ __global__ __launch_bounds__(256) void k_warp_volume(
   *reinterpret_cast<bf16x8*>(out + row * C + c0) = o;
 }
 
+// affine[b] = S^-1 * inv(prev2glob[b]) * cur2glob[b] * S with S = voxel index ->
+// metric (diag(step), first centre): the whole coordinate chain of
+// align_after_lss in voxel-index units, in double, one thread per sample -- so the
+// warp needs no host round trip for 4x4 algebra.
+__global__ void k_warp_affine(const float* __restrict__ cur2glob,
+                              const float* __restrict__ prev2glob, int stride,
+                              double fx, double fy, double fz, double sx, double sy,
+                              double sz, float* __restrict__ A, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  double m[4][8];
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) {
+      m[i][j] = prev2glob[(int64_t)b * stride + i * 4 + j];
+      m[i][4 + j] = i == j ? 1.0 : 0.0;
+    }
+  for (int c = 0; c < 4; ++c) {  // Gauss-Jordan, partial pivoting
+    int piv = c;
+    for (int r = c + 1; r < 4; ++r)
+      if (fabs(m[r][c]) > fabs(m[piv][c])) piv = r;
+    for (int j = 0; j < 8; ++j) {
+      const double t = m[c][j];
+      m[c][j] = m[piv][j];
+      m[piv][j] = t;
+    }
+    const double inv = 1.0 / m[c][c];
+    for (int j = 0; j < 8; ++j) m[c][j] *= inv;
+    for (int r = 0; r < 4; ++r) {
+      if (r == c) continue;
+      const double f = m[r][c];
+      for (int j = 0; j < 8; ++j) m[r][j] -= f * m[c][j];
+    }
+  }
+  const double first[3] = {fx, fy, fz}, step[3] = {sx, sy, sz};
+  for (int i = 0; i < 3; ++i) {
+    double t[4];  // row i of inv(prev) * cur
+    for (int j = 0; j < 4; ++j) {
+      t[j] = 0.0;
+      for (int k = 0; k < 4; ++k)
+        t[j] += m[i][4 + k] * (double)cur2glob[(int64_t)b * stride + k * 4 + j];
+    }
+    // metric point = step * idx + first;  past idx = (T p - first) / step
+    double off = t[3];
+    for (int j = 0; j < 3; ++j) {
+      A[b * 12 + i * 4 + j] = (float)(t[j] * step[j] / step[i]);
+      off += t[j] * first[j];
+    }
+    A[b * 12 + i * 4 + 3] = (float)((off - first[i]) / step[i]);
+  }
+}
+
 // zero the halo rows of a padded grid (after a row-wise GEMM wrote its bias there)
 __global__ __launch_bounds__(256) void k_zero_halo(bf16_t* __restrict__ rows, int planes,
                                                     int Zp, int Yp, int Xp, int C) {
@@ -240,6 +291,21 @@ int veon_volume_warp_bf16(const void* in_padded, void* out_padded,
                      static_cast<hipStream_t>(stream),
                      static_cast<const bf16_t*>(in_padded),
                      static_cast<bf16_t*>(out_padded), affine, B, Z, Y, X, C);
+  return launch_status();
+}
+
+int veon_warp_affine(const float* cur2glob, const float* prev2glob, int mat_stride,
+                     const double* first_xyz, const double* step_xyz, float* affine,
+                     int B, void* stream) {
+  if (B <= 0 || mat_stride < 16 || !cur2glob || !prev2glob || !first_xyz || !step_xyz ||
+      !affine)
+    return VEON_ERR_BAD_ARG;
+  for (int i = 0; i < 3; ++i)
+    if (!(step_xyz[i] > 0.0)) return VEON_ERR_BAD_ARG;
+  hipLaunchKernelGGL(k_warp_affine, dim3((B + 63) / 64), dim3(64), 0,
+                     static_cast<hipStream_t>(stream), cur2glob, prev2glob, mat_stride,
+                     first_xyz[0], first_xyz[1], first_xyz[2], step_xyz[0], step_xyz[1],
+                     step_xyz[2], affine, B);
   return launch_status();
 }
 

@@ -1,7 +1,8 @@
 """``AlignNetOcc3D`` -- the 3-D occupancy decoder that owns the lift: mirror of
-mmdet3d/models/semantic_net/side_adapter/align_net_occ3d.py:207-361 for the
-single-frame case (``num_temporal == 1``; the temporal fusion of SURVEY 8 row f4
-is not built).
+mmdet3d/models/semantic_net/side_adapter/align_net_occ3d.py:207-361, with the
+temporal fusion of SURVEY 8 row f4 (``num_temporal > 1``: ``temporal_fusion`` is a
+``TemporalFusionMultiFrame``, applied after the lift of block ``tf_layers`` = 0 to
+the current volume and the aligned volumes of the past frames).
 
 Same constructor, sub-module / parameter names (``fusion_layers.layer_N``,
 ``layers_3d_body.N``, ``occupancy_pred``, ``feat_pred``) and method contracts
@@ -25,6 +26,7 @@ import torch.nn as nn
 from ... import conv3d_ops
 from .align_net_body import AlignBody3D, PredHead3DOcc, PredHead3DSem, ResBlock3D
 from .fusion_layers import build_fusion_layer_lift
+from .temporal_fusion import TemporalFusionMultiFrame
 
 
 class AlignNetOcc3D(nn.Module):
@@ -32,8 +34,6 @@ class AlignNetOcc3D(nn.Module):
                  layer_lifting_map=None, fusion_type='add', layer_depth=5,
                  num_temporal=1):
         super().__init__()
-        if num_temporal != 1:
-            raise NotImplementedError('temporal fusion (num_temporal > 1) is not built')
         self.fusion_map = {int(k): (int(i), int(j)) for i, j, k in
                            [x.split('->') for x in layer_lifting_map]}
         self.fusion_layers = nn.ModuleDict({
@@ -45,7 +45,8 @@ class AlignNetOcc3D(nn.Module):
         self.occupancy_pred = PredHead3DOcc(embed_dim, 2)
         self.feat_pred = PredHead3DSem(embed_dim, clip_outdim)
         self.tf_layers = 0
-        self.temporal_fusion = None
+        self.temporal_fusion = TemporalFusionMultiFrame(
+            channels=embed_dim, seqs=num_temporal - 1) if num_temporal > 1 else None
         self.use_hip = True
         # the body runner shares the ModuleList (not registered twice)
         body = AlignBody3D.__new__(AlignBody3D)
@@ -124,8 +125,11 @@ class AlignNetOcc3D(nn.Module):
 
     def forward(self, sem_feat, clip_features: List, supp_features: List, depth,
                 img_metas: List, occ_feat_prevs: List = None):
-        if occ_feat_prevs:
-            raise NotImplementedError('temporal fusion is not built')
+        if occ_feat_prevs is not None and len(occ_feat_prevs) == 0:
+            occ_feat_prevs = None
+        if occ_feat_prevs is not None and self.temporal_fusion is None:
+            raise ValueError('occ_feat_prevs given but the decoder was built with '
+                             'num_temporal=1')
         depth = self.prepare_depth(depth)
         if self.lss_view_transformer.mode == 'nuscenes':
             img_metas = self.prepare_meta(img_metas)
@@ -137,20 +141,49 @@ class AlignNetOcc3D(nn.Module):
             if self.lss_view_transformer._can_fuse_ds(sem_feat):
                 x = self.fuse(0, None, clip_features, supp_features, depth, img_metas,
                               (h, w), (H, W), out_volume=vol)
+                if occ_feat_prevs is not None:
+                    x = self._temporal(x, occ_feat_prevs)
                 x = self.__dict__['_body'](x, return_volume=True)
                 return {'bin_occ': self.occupancy_pred(x), 'feat_occ': self.feat_pred(x)}
         x = None
         for idx, layer_3d in enumerate(self.layers_3d_body):
             x = self.fuse(idx, x, clip_features, supp_features, depth, img_metas,
                           (h, w), (H, W))
+            if idx == self.tf_layers and occ_feat_prevs is not None:
+                x = self._temporal(x, occ_feat_prevs)
             x = layer_3d(x)
         return {'bin_occ': self.occupancy_pred(x), 'feat_occ': self.feat_pred(x)}
 
-    def forward_early(self, sem_feat, clip_features, supp_features, depth, img_metas):
+    def _temporal(self, x, prevs):
+        """``temporal_fusion`` on whatever the two sides are: PaddedVolumes stay on
+        the MFMA path (fp32 ROCm tensors are packed when it is available),
+        otherwise the PyTorch definition runs on fp32 tensors."""
+        tf = self.temporal_fusion
+        padded = conv3d_ops.PaddedVolume
+        if self.use_hip and tf.hip_ok(x) and all(
+                isinstance(p, padded) or p.is_cuda for p in prevs):
+            vols = [v if isinstance(v, padded) else conv3d_ops.pack(v)
+                    for v in [x] + list(prevs)]
+            out = tf(vols[0], vols[1:])
+            return out if isinstance(x, padded) else conv3d_ops.unpack(out)
+        vals = [conv3d_ops.unpack(v) if isinstance(v, padded) else v
+                for v in [x] + list(prevs)]
+        out = tf(vals[0], vals[1:])
+        return conv3d_ops.pack(out) if isinstance(x, padded) else out
+
+    def forward_early(self, sem_feat, clip_features, supp_features, depth, img_metas,
+                      out_volume=None):
+        """The lifted volume of a (past) frame, before any 3-D layer
+        (align_net_occ3d.py:268-280).  ``out_volume`` (a PaddedVolume of the
+        max-pooled shape): have the lift write there and return it."""
         depth = self.prepare_depth(depth)
         if self.lss_view_transformer.mode == 'nuscenes':
             img_metas = self.prepare_meta(img_metas)
         h, w = clip_features[1].shape[2:]
         H, W = sem_feat.shape[2:]
+        if out_volume is not None and not (
+                self._fast_path(sem_feat)
+                and self.lss_view_transformer._can_fuse_ds(sem_feat)):
+            raise ValueError('out_volume needs the fused lift + max-pool path')
         return self.fuse(0, None, clip_features, supp_features, depth, img_metas,
-                         (h, w), (H, W))
+                         (h, w), (H, W), out_volume=out_volume)

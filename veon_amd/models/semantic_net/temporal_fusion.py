@@ -286,13 +286,9 @@ def align_after_lss(occ_feat, adj_metas, grid_config, ds_feat):
     if _fast(occ_feat):
         B, C, Z, Y, X = occ_feat.shape
         first, step = voxel_centres(grid_config, ds_feat, (Z, Y, X))
-        T = prev_from_cur([m.double().cpu() for m in adj_metas])
-        # voxel index (x,y,z) -> metric -> past frame -> past voxel index
-        to_metric = torch.eye(4, dtype=torch.float64)
-        to_metric[:3, :3] = torch.diag(torch.tensor(step, dtype=torch.float64))
-        to_metric[:3, 3] = torch.tensor(first, dtype=torch.float64)
-        A = torch.linalg.inv(to_metric) @ T @ to_metric
-        return conv3d_ops.warp_volume(occ_feat, A[:, :3, :].float().contiguous())
+        dev = occ_feat.device
+        A = conv3d_ops.warp_affine(adj_metas[0].to(dev), adj_metas[1].to(dev), first, step)
+        return conv3d_ops.warp_volume(occ_feat, A)
     B, C, Z, Y, X = occ_feat.shape
     dev, dt = occ_feat.device, occ_feat.dtype
     first, step = voxel_centres(grid_config, ds_feat, (Z, Y, X))

@@ -15,8 +15,16 @@ package's mirrors (single frame, inference):
 
 NOT included (third-party / not rebuilt): the timm side-adapter ViT, its mask
 decoder and the 2-D segmentation outputs (``sem_embed_ds`` only supplies a shape
-to the decoder), the text encoder (class embeddings are an input), the temporal
-path.  Weights are whatever the sub-modules hold (random unless loaded).
+to the decoder), the text encoder (class embeddings are an input).  Weights are
+whatever the sub-modules hold (random unless loaded).
+
+Temporal (``num_temporal > 1``, san_in_veon_temporal.py:158-173): ``lift_frame``
+gives a past frame's lifted volume (``forward_early``), ``align`` warps it into
+the current ego frame (``align_after_lss``), and ``forward(...,
+prev_volumes=[...])`` fuses them after the current lift.  The reference recomputes
+the past frames' encoders at every step; a streaming deployment keeps each frame's
+lifted volume and only re-warps it -- same numbers, both are possible with this
+interface.
 
 The two encoder branches are independent and neither fills the chip, so they run
 on two HIP streams (``two_streams=True``).
@@ -36,7 +44,8 @@ class VeonOccupancyPath(nn.Module):
                  encoder='vitb', n_classes=17, clip_width=768, clip_layers=12,
                  clip_heads=12, clip_first_tail=9, clip_proj_dim=512, embed_dim=256,
                  occ_size=(16, 200, 200), bf16_heads=True, two_streams=True,
-                 hsa_dim=384, hsa_fusion_map=('0->3->3', '1->6->6', '2->9->9')):
+                 hsa_dim=384, hsa_fusion_map=('0->3->3', '1->6->6', '2->9->9'),
+                 num_temporal=1):
         super().__init__()
         from .. import synthetic
         grid_config = grid_config or synthetic.GRID_VEON
@@ -64,7 +73,7 @@ class VeonOccupancyPath(nn.Module):
         self.occ_decoder = AlignNetOcc3D(
             clip_dim=clip_width, hsa_dim=hsa_dim, embed_dim=embed_dim,
             clip_outdim=clip_proj_dim, layer_lifting_map=['%d->0->0' % clip_layers],
-            fusion_type='cat_fusion', layer_depth=4)
+            fusion_type='cat_fusion', layer_depth=4, num_temporal=num_temporal)
         self.occ_decoder.lss_view_transformer = self.view_transformer
         self.occ_decoder.num_frame, self.occ_decoder.num_camera = 1, num_cam
         self.ov_classifier_weight = nn.Parameter(torch.randn(n_classes, clip_proj_dim))
@@ -101,11 +110,8 @@ class VeonOccupancyPath(nn.Module):
         feats = self.clip_rec_head.update_remaining_clip_feats(feats, None, attns)
         return feats, supp
 
-    def forward(self, images, img_metas):
-        """images (B, N, 3, H, W); img_metas = (sensor2egos, ego2globals, intrins,
-        post_rots, post_trans, bda) as the reference's ``img[1:7]``.  Returns
-        ``bin_occ`` / ``sem_occ`` at ``occ_size`` and ``occ_pred_cls``."""
-        B, N = images.shape[:2]
+    def _branches(self, images):
+        """Both encoder branches of one frame -> (CLIP feature dict, supp, depth)."""
         img = images.flatten(0, 1)
         if self.two_streams and img.is_cuda:
             if self.__dict__['_side'] is None:
@@ -121,6 +127,44 @@ class VeonOccupancyPath(nn.Module):
         else:
             feats, supp = self.clip_features(img)
             depth = self.estimate_depth(img)
+        return feats, supp, depth
+
+    def lift_frame(self, images, img_metas, out_volume=None):
+        """Lifted, max-pooled volume of one frame before any 3-D layer
+        (``occ_decoder.forward_early``, san_in_veon_temporal.py:166-168): what a
+        later step needs of this frame.  On the native path the result is a
+        PaddedVolume (a new one unless ``out_volume`` is given)."""
+        from .. import conv3d_ops
+        B, N = images.shape[:2]
+        feats, supp, depth = self._branches(images)
+        hf, wf = self.input_size[0] // 16, self.input_size[1] // 16
+        sem_embed_ds = images.new_zeros((B * N, 1, hf, wf))
+        metas = list(img_metas[:5]) + [img_metas[5][None]]
+        dec = self.occ_decoder
+        if dec._fast_path(sem_embed_ds) and self.view_transformer._can_fuse_ds(sem_embed_ds):
+            if out_volume is None:
+                like = dec._lift_volume(B, dec.layers_3d_body[0].conv1.conv.in_channels,
+                                        images.device)
+                out_volume = like.like()
+            return dec.forward_early(sem_embed_ds, feats, [supp], depth, metas,
+                                     out_volume=out_volume)
+        return dec.forward_early(sem_embed_ds, feats, [supp], depth, metas)
+
+    def align(self, volume, adj_metas):
+        """``align_after_lss``: a past frame's volume resampled in the current ego
+        frame; ``adj_metas`` = [lidarego2global (B,1,4,4), lidaregoprev2global]."""
+        from .semantic_net.temporal_fusion import align_after_lss
+        vt = self.view_transformer
+        return align_after_lss(volume, adj_metas, vt.grid_config, tuple(vt.ds))
+
+    def forward(self, images, img_metas, prev_volumes=None):
+        """images (B, N, 3, H, W); img_metas = (sensor2egos, ego2globals, intrins,
+        post_rots, post_trans, bda) as the reference's ``img[1:7]``;
+        ``prev_volumes``: aligned lifted volumes of the past frames, newest first
+        (the reference's ``occ_feat_prevs``).  Returns ``bin_occ`` / ``sem_occ`` at
+        ``occ_size`` and ``occ_pred_cls``."""
+        B, N = images.shape[:2]
+        feats, supp, depth = self._branches(images)
         hf, wf = self.input_size[0] // 16, self.input_size[1] // 16
         sem_embed_ds = images.new_zeros((B * N, 1, hf, wf))   # shape carrier only
         metas = list(img_metas[:5]) + [img_metas[5][None]]
@@ -131,14 +175,16 @@ class VeonOccupancyPath(nn.Module):
             depth2 = dec.prepare_depth(depth)
             metas2 = dec.prepare_meta(metas)
             vol = dec._lift_volume(depth2.shape[0], dec.layers_3d_body[0].conv1.conv.in_channels,
-                                   img.device)
+                                   images.device)
             x = dec.fuse(0, None, feats, [supp], depth2, metas2, None, (hf, wf),
                          out_volume=vol)
+            if prev_volumes:
+                x = dec._temporal(x, prev_volumes)
             x = dec.__dict__['_body'](x, return_volume=True)
             bin_occ = dec.occupancy_pred(x)
             feat = dec.feat_pred(x, return_volume=True)
         else:
-            out = dec(sem_embed_ds, feats, [supp], depth, metas)
+            out = dec(sem_embed_ds, feats, [supp], depth, metas, prev_volumes)
             bin_occ, feat = out['bin_occ'], out['feat_occ']
         sem_occ = semantic_inference_3d_fused(self.ov_classifier_weight, feat, self.occ_size)
         bin_occ = F.interpolate(bin_occ, size=tuple(self.occ_size), mode='trilinear',
