@@ -73,3 +73,31 @@ def test_align_identity_transform_is_a_copy():
     eye = torch.eye(4)[None, None]
     out = tfm.align_after_lss(occ, [eye, eye], grid, (2, 2, 2))
     assert torch.allclose(out, occ, atol=1e-5)
+
+
+def test_depth_cache_wire_format(tmp_path):
+    """layout and payload of the reference's depth cache
+    (veon_depth_cache.py:146-157 writes, loading.py:1259-1262 reads)."""
+    import os
+    from veon_amd import depth_cache
+    home = str(tmp_path)
+    toks = ['ab12cd34-CAM_FRONT', 'ab12cd34-CAM_BACK_LEFT']
+    depth = torch.rand(1, 2, 8, 22) * 80
+    written = depth_cache.store(home, toks, depth)
+    assert written == [os.path.join(home, 'ab', 'ab12cd34', t + '.tensor') for t in toks]
+    # the reference's reader is a bare torch.load of each file
+    raw = torch.load(written[0])
+    assert raw.dtype == torch.float32 and raw.shape == (8, 22) and torch.equal(raw, depth[0, 0])
+    assert os.path.getsize(written[0]) < 8 * 22 * 4 + 2048    # the map, not the batch
+    assert torch.equal(depth_cache.load(home, toks), depth[0])
+    # existing files are kept (the reference `continue`s), unless asked
+    assert depth_cache.store(home, toks, depth * 2) == []
+    assert torch.equal(depth_cache.load(home, toks), depth[0])
+    assert len(depth_cache.store(home, toks, depth * 2, overwrite=True)) == 2
+    # a file written the way the reference writes it is read back
+    other = 'ff00aa11-CAM_BACK'
+    os.makedirs(os.path.dirname(depth_cache.cache_path(home, other)))
+    torch.save(depth[0][1].cpu(), depth_cache.cache_path(home, other))
+    assert torch.equal(depth_cache.load(home, [other])[0], depth[0, 1])
+    with pytest.raises(FileNotFoundError):
+        depth_cache.load(home, ['00000000-CAM_FRONT'])

@@ -204,3 +204,48 @@ def test_temporal_decoder_fast_path_agrees_with_modules():
     for key in ('bin_occ', 'feat_occ'):
         rel = ((fast[key] - slow[key]).norm() / slow[key].norm()).item()
         assert rel < 4e-2, (key, rel)
+
+
+def test_occupancy_path_temporal_loop_and_cached_depth(tmp_path):
+    """VeonOccupancyPath(num_temporal=2): lift_frame -> align -> forward(prev_volumes)
+    runs on the native kernels; a depth map stored in / loaded from the depth
+    cache replaces the depth branch with the same result; an identity-aligned copy
+    of a kept volume equals the kept volume."""
+    from veon_amd import _lib, depth_cache, synthetic
+    from veon_amd.models.veon_occ import VeonOccupancyPath
+    torch.manual_seed(0)
+    size, ncam = (64, 176), 2
+    net = VeonOccupancyPath(
+        input_size=size, num_cam=ncam, encoder='vitb', clip_width=64, clip_layers=4,
+        clip_heads=1, clip_first_tail=2, clip_proj_dim=64, embed_dim=128,
+        occ_size=(4, 20, 20), hsa_dim=64, hsa_fusion_map=('0->1->1', '1->2->2'),
+        num_temporal=2,
+        grid_config={'x': [-10.0, 10.0, 1.0], 'y': [-10.0, 10.0, 1.0],
+                     'z': [-1.0, 3.0, 1.0], 'depth': [1.0, 13.0, 1.0]}).to(DEV).eval()
+    geom = [t.to(DEV) for t in synthetic.rig_inputs(synthetic.make_rig(1, ncam, size))]
+    cur = torch.randn(1, ncam, 3, *size, device=DEV)
+    past = torch.randn(1, ncam, 3, *size, device=DEV)
+    eye = torch.eye(4, device=DEV)[None, None]
+    move = eye.clone()
+    move[0, 0, :3, 3] = torch.tensor([1.0, 0.5, 0.0])
+    before = dict(_lib.CALLS)
+    with torch.no_grad():
+        kept = net.lift_frame(past, geom)
+        assert isinstance(kept, conv3d_ops.PaddedVolume)
+        same = net.align(kept, [eye, eye])
+        assert torch.equal(same.rows, kept.rows)
+        out = net(cur, geom, [net.align(kept, [eye, move])])
+        single = net(cur, geom)
+        # depth cache round trip in place of the depth branch
+        depth = net.estimate_depth(cur.flatten(0, 1))
+        toks = ['0123abcd-CAM_FRONT', '0123abcd-CAM_BACK']
+        depth_cache.store(str(tmp_path), toks, depth)
+        cached = depth_cache.load(str(tmp_path), toks, DEV)[None]
+        again = net(cur, geom, [net.align(kept, [eye, move])], depth=cached)
+    ran = {k for k, v in _lib.CALLS.items() if v > before.get(k, 0)}
+    assert {'veon_volume_warp_bf16', 'veon_warp_affine', 'veon_deform_attention_bf16',
+            'veon_volume_zero_halo_bf16'} <= ran, ran
+    assert out['sem_occ'].shape == (1, 17, 4, 20, 20)
+    assert torch.isfinite(out['sem_occ']).all() and torch.isfinite(out['bin_occ']).all()
+    assert not torch.equal(out['sem_occ'], single['sem_occ'])
+    assert torch.equal(again['sem_occ'], out['sem_occ'])

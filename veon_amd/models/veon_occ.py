@@ -110,9 +110,15 @@ class VeonOccupancyPath(nn.Module):
         feats = self.clip_rec_head.update_remaining_clip_feats(feats, None, attns)
         return feats, supp
 
-    def _branches(self, images):
-        """Both encoder branches of one frame -> (CLIP feature dict, supp, depth)."""
+    def _branches(self, images, depth=None):
+        """Both encoder branches of one frame -> (CLIP feature dict, supp, depth).
+        ``depth`` (B, N, H/2, W/2): cached metric depth (veon_amd/depth_cache.py)
+        used instead of the depth encoder, as the reference's ``use_depth_pred``
+        data pipeline does."""
         img = images.flatten(0, 1)
+        if depth is not None:
+            feats, supp = self.clip_features(img)
+            return feats, supp, depth.to(img.device, torch.float32)
         if self.two_streams and img.is_cuda:
             if self.__dict__['_side'] is None:
                 self.__dict__['_side'] = torch.cuda.Stream()
@@ -129,14 +135,14 @@ class VeonOccupancyPath(nn.Module):
             depth = self.estimate_depth(img)
         return feats, supp, depth
 
-    def lift_frame(self, images, img_metas, out_volume=None):
+    def lift_frame(self, images, img_metas, out_volume=None, depth=None):
         """Lifted, max-pooled volume of one frame before any 3-D layer
         (``occ_decoder.forward_early``, san_in_veon_temporal.py:166-168): what a
         later step needs of this frame.  On the native path the result is a
         PaddedVolume (a new one unless ``out_volume`` is given)."""
         from .. import conv3d_ops
         B, N = images.shape[:2]
-        feats, supp, depth = self._branches(images)
+        feats, supp, depth = self._branches(images, depth)
         hf, wf = self.input_size[0] // 16, self.input_size[1] // 16
         sem_embed_ds = images.new_zeros((B * N, 1, hf, wf))
         metas = list(img_metas[:5]) + [img_metas[5][None]]
@@ -157,14 +163,14 @@ class VeonOccupancyPath(nn.Module):
         vt = self.view_transformer
         return align_after_lss(volume, adj_metas, vt.grid_config, tuple(vt.ds))
 
-    def forward(self, images, img_metas, prev_volumes=None):
+    def forward(self, images, img_metas, prev_volumes=None, depth=None):
         """images (B, N, 3, H, W); img_metas = (sensor2egos, ego2globals, intrins,
         post_rots, post_trans, bda) as the reference's ``img[1:7]``;
         ``prev_volumes``: aligned lifted volumes of the past frames, newest first
         (the reference's ``occ_feat_prevs``).  Returns ``bin_occ`` / ``sem_occ`` at
         ``occ_size`` and ``occ_pred_cls``."""
         B, N = images.shape[:2]
-        feats, supp, depth = self._branches(images)
+        feats, supp, depth = self._branches(images, depth)
         hf, wf = self.input_size[0] // 16, self.input_size[1] // 16
         sem_embed_ds = images.new_zeros((B * N, 1, hf, wf))   # shape carrier only
         metas = list(img_metas[:5]) + [img_metas[5][None]]
