@@ -1,0 +1,41 @@
+#!/usr/bin/env python
+"""N forwards of the whole occupancy path (VeonOccupancyPath, one stream) and
+nothing else -- meant to run under `rocprofv3 --kernel-trace --stats`, so that
+(sum of kernel durations) / N is the GPU-busy time of one step and can be held
+against the wall time printed here.  Not a test."""
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from veon_amd import synthetic  # noqa: E402
+from veon_amd.models.veon_occ import VeonOccupancyPath  # noqa: E402
+
+
+def main():
+    n = int(os.environ.get('N', 20))
+    dev, size = 'cuda:0', (256, 704)
+    torch.manual_seed(0)
+    net = VeonOccupancyPath(input_size=size, encoder='vitb').to(dev).eval()
+    net.two_streams = os.environ.get('TWO_STREAMS', '0') == '1'
+    geom = [t.to(dev) for t in synthetic.rig_inputs(synthetic.make_rig(1, 6, size))]
+    images = torch.randn(1, 6, 3, *size, device=dev)
+    with torch.no_grad():
+        for _ in range(3):
+            net(images, geom)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            net(images, geom)
+        t_issue = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        t_all = time.perf_counter() - t0
+    print('%d forwards (+3 warm-up): wall %.2f ms per step, host issue time %.2f ms per step'
+          % (n, t_all / n * 1e3, t_issue / n * 1e3))
+
+
+if __name__ == '__main__':
+    main()
