@@ -249,3 +249,20 @@ def test_occupancy_path_temporal_loop_and_cached_depth(tmp_path):
     assert torch.isfinite(out['sem_occ']).all() and torch.isfinite(out['bin_occ']).all()
     assert not torch.equal(out['sem_occ'], single['sem_occ'])
     assert torch.equal(again['sem_occ'], out['sem_occ'])
+
+
+def test_native_caches_follow_a_state_dict_load():
+    """folded / packed weights cached by the MFMA path are rebuilt after
+    load_state_dict (a stale cache would silently keep the old weights)."""
+    torch.manual_seed(2)
+    C = 128
+    a = tfm.TemporalFusionMultiFrame(C, seqs=1).to(DEV).eval()
+    b = tfm.TemporalFusionMultiFrame(C, seqs=1).to(DEV).eval()
+    cur = torch.randn(1, C, 2, 6, 7, device=DEV)
+    prev = [torch.randn(1, C, 2, 6, 7, device=DEV)]
+    with torch.no_grad():
+        ya = a.forward_fast(cur, prev)
+        yb = b.forward_fast(cur, prev)
+        assert not torch.allclose(ya, yb)
+        b.load_state_dict(a.state_dict())
+        assert torch.equal(b.forward_fast(cur, prev), ya)

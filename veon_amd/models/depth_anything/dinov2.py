@@ -277,6 +277,11 @@ class DinoVisionTransformer(nn.Module):
         self._pos_cache = {}
         return super()._load_from_state_dict(*args, **kwargs)
 
+    def _apply(self, fn, *args, **kwargs):   # .to() / .cuda() / .half()
+        self._hip_weights = None
+        self._pos_cache = {}
+        return super()._apply(fn, *args, **kwargs)
+
     def _use_hip(self, x):
         return (self.use_hip and x.is_cuda and not self.training
                 and not torch.is_grad_enabled()

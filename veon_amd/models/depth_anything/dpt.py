@@ -14,6 +14,7 @@ import torch.nn.functional as F
 
 from ... import conv3d_ops, vit_ops
 from ..builder import register_neck
+from .._native_cache import NativeCacheMixin
 from .dinov2 import DINOv2Adaptor
 
 
@@ -54,7 +55,9 @@ def _hip_cache(mod, name, conv):
     return cache[name]
 
 
-class ResidualConvUnit(nn.Module):
+class ResidualConvUnit(NativeCacheMixin, nn.Module):
+    _native_cache = ('_hip_convs',)
+
     def __init__(self, features, bn=False):
         super().__init__()
         self.bn = bn
@@ -73,10 +76,6 @@ class ResidualConvUnit(nn.Module):
             out = self.bn2(out)
         return out + x
 
-    def train(self, mode=True):
-        self.__dict__.pop('_hip_convs', None)
-        return super().train(mode)
-
     def hip_forward(self, img, scratch):
         """conv2(relu(conv1(relu(x)))) + x on a PaddedImage: ReLU of the input
         is one elementwise pass (the zero halo stays zero), bias + ReLU and
@@ -86,7 +85,9 @@ class ResidualConvUnit(nn.Module):
         return _hip_cache(self, 'conv2', self.conv2)(u, resid=img, tag=2)
 
 
-class FeatureFusionBlock(nn.Module):
+class FeatureFusionBlock(NativeCacheMixin, nn.Module):
+    _native_cache = ('_hip_bufs', '_hip_1x1')
+
     """util/blocks.py:86-148 (expand=False, align_corners=True)."""
 
     def __init__(self, features, bn=False, size=None):
@@ -102,11 +103,6 @@ class FeatureFusionBlock(nn.Module):
         if key not in bufs:
             bufs[key] = conv3d_ops.PaddedImage(B, C, H, W, device)
         return bufs[key]
-
-    def train(self, mode=True):
-        self.__dict__.pop('_hip_bufs', None)
-        self.__dict__.pop('_hip_1x1', None)
-        return super().train(mode)
 
     def hip_ok(self, x):
         u1, u2 = self.resConfUnit1, self.resConfUnit2
@@ -161,7 +157,9 @@ def _make_scratch(in_shape, out_shape):
     return scratch
 
 
-class DPTHead(nn.Module):
+class DPTHead(NativeCacheMixin, nn.Module):
+    _native_cache = ('_hip_convs', '_hip_in', '_hip_tail')
+
     def __init__(self, in_channels, features=256, use_bn=False,
                  out_channels=[256, 512, 1024, 1024], use_clstoken=False):
         super().__init__()
@@ -214,12 +212,6 @@ class DPTHead(nn.Module):
         out = F.interpolate(out, (int(patch_h * 14), int(patch_w * 14)),
                             mode='bilinear', align_corners=True)
         return s.output_conv2(out)
-
-    def train(self, mode=True):
-        self.__dict__.pop('_hip_convs', None)
-        self.__dict__.pop('_hip_in', None)
-        self.__dict__.pop('_hip_tail', None)
-        return super().train(mode)
 
     def _hip_refine(self, l1, l2, l3, l4, patch_h, patch_w):
         """Fusion blocks + output convs entirely in the padded channels-last

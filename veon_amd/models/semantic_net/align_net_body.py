@@ -20,10 +20,13 @@ import torch
 import torch.nn as nn
 
 from ... import conv3d_ops, vit_ops
+from .._native_cache import NativeCacheMixin
 
 
-class ConvModule3d(nn.Module):
+class ConvModule3d(NativeCacheMixin, nn.Module):
     """Conv3d -> BN3d -> ReLU with mmcv ConvModule's attribute names."""
+
+    _native_cache = ('_hip', '_hip3', '_hip_out')
 
     def __init__(self, cin, cout, kernel_size=3, stride=1, padding=1, bias=False,
                  norm=True, act=True):
@@ -260,6 +263,10 @@ class AlignBody3D(nn.Module):
     def _load_from_state_dict(self, *args, **kwargs):
         self._hip = None
         return super()._load_from_state_dict(*args, **kwargs)
+
+    def _apply(self, fn, *args, **kwargs):   # .to() / .cuda() / .half()
+        self._hip = None
+        return super()._apply(fn, *args, **kwargs)
 
     def _use_hip(self, x):
         return (self.use_hip and x.is_cuda and not self.training

@@ -64,6 +64,10 @@ class AlignNetOcc3D(nn.Module):
         self.__dict__['_body'].invalidate_hip_cache()
         return super()._load_from_state_dict(*args, **kwargs)
 
+    def _apply(self, fn, *args, **kwargs):   # .to() / .cuda() / .half()
+        self.__dict__['_body'].invalidate_hip_cache()
+        return super()._apply(fn, *args, **kwargs)
+
     # ------------------------------------------------------------ preparation
     def prepare_depth(self, depth):
         depth_ds = self.lss_view_transformer.downsample_depth(depth, downsample=8)

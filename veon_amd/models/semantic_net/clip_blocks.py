@@ -212,6 +212,11 @@ class ClipVisualTrunk(nn.Module):
         self._pos_cache = {}
         return super()._load_from_state_dict(*args, **kwargs)
 
+    def _apply(self, fn, *args, **kwargs):   # .to() / .cuda() / .half()
+        self._hip_cache = {}
+        self._pos_cache = {}
+        return super()._apply(fn, *args, **kwargs)
+
     def _pos_embed(self, h, w):
         pe = self.positional_embedding
         if (h, w) == self.grid_size:
@@ -299,6 +304,14 @@ class ClipRecHead(nn.Module):
     def train(self, mode=True):
         self._hip_cache = {}
         return super().train(mode)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self._hip_cache = {}
+        return super()._load_from_state_dict(*args, **kwargs)
+
+    def _apply(self, fn, *args, **kwargs):
+        self._hip_cache = {}
+        return super()._apply(fn, *args, **kwargs)
 
     @staticmethod
     def _save(outputs, idx, tokens, hw):

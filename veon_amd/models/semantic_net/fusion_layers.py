@@ -12,6 +12,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ... import vit_ops
+from .._native_cache import NativeCacheMixin
 
 
 class LayerNorm(nn.Module):
@@ -49,7 +50,9 @@ class AddFusionLift(nn.Module):
         return self.relu(x + y)
 
 
-class CatFusionLift(nn.Module):
+class CatFusionLift(NativeCacheMixin, nn.Module):
+    _native_cache = ('_hip',)
+
     """LN + 1x1 conv of cat(x1, x2) -> C/4 channels, LN + 1x1 conv of x2 ->
     3C/4, concatenated, ReLU; both inputs are first resized to the lift's
     feature-map shape."""
@@ -66,10 +69,6 @@ class CatFusionLift(nn.Module):
         # view), which the lift consumes as half-precision feature rows without
         # any copy.  None = the reference's fp32 PyTorch formulation.
         self.hip_dtype = None
-
-    def train(self, mode=True):
-        self.__dict__.pop('_hip', None)
-        return super().train(mode)
 
     def _hip_ok(self, x1, x2):
         c1 = self.input_proj_1[1]

@@ -23,6 +23,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ... import conv3d_ops, vit_ops
+from .._native_cache import NativeCacheMixin
 
 
 def _interp(x, **kw):
@@ -33,17 +34,15 @@ def _interp(x, **kw):
     return F.interpolate(x, **kw)
 
 
-class FeedForward(nn.Module):
+class FeedForward(NativeCacheMixin, nn.Module):
+    _native_cache = ('_hip',)
+
     def __init__(self, dim, hidden_dim, out_dim=-1):
         super().__init__()
         out_dim = dim if out_dim == -1 else out_dim
         self.net = nn.Sequential(nn.LayerNorm(dim), nn.Linear(dim, hidden_dim), nn.GELU(),
                                  nn.Linear(hidden_dim, out_dim))
         self.conv_dtype = None   # set with the ConvBlocks (set_conv_dtype)
-
-    def train(self, mode=True):
-        self.__dict__.pop('_hip', None)
-        return super().train(mode)
 
     def forward(self, x):
         ln, fc1, _, fc2 = self.net
@@ -67,7 +66,9 @@ class FeedForward(nn.Module):
         return self.net(x)
 
 
-class ConvBlock(nn.Module):
+class ConvBlock(NativeCacheMixin, nn.Module):
+    _native_cache = ('_hip',)
+
     """tokens (B, L, dim) on an H x W map: conv3x3 -> GELU -> LN -> conv3x3 -> LN
     (:31-52)."""
 
@@ -81,10 +82,6 @@ class ConvBlock(nn.Module):
         self.ln2 = nn.LayerNorm(out_dim)
         self.dim, self.h_dim, self.out_dim = dim, hidden_dim, out_dim
         self.conv_dtype = None
-
-    def train(self, mode=True):
-        self.__dict__.pop('_hip', None)
-        return super().train(mode)
 
     def _hip_ok(self, x):
         return (self.conv_dtype == torch.bfloat16 and x.is_cuda

@@ -29,6 +29,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ... import conv3d_ops, vit_ops
+from .._native_cache import NativeCacheMixin
 from .align_net_body import ConvModule3d
 
 
@@ -95,7 +96,7 @@ class TemporalFusionMultiFrameMiddle3x3Seq(nn.Module):
         return ref, past
 
 
-class TemporalDeformable(nn.Module):
+class TemporalDeformable(NativeCacheMixin, nn.Module):
     """Deformable cross-frame attention (align_net_occ3d.py:89-204): queries and
     sampling offsets from one volume, keys/values sampled trilinearly from the
     other at ``num_samples`` points per head, softmax over the samples."""
@@ -152,13 +153,7 @@ class TemporalDeformable(nn.Module):
         return self.out_activate(self.final_norm(self.out_proj(fused)))
 
     # ------------------------------------------------------------- MFMA path
-    def train(self, mode=True):
-        self.__dict__['_hip'] = None
-        return super().train(mode)
-
-    def _load_from_state_dict(self, *args, **kwargs):
-        self.__dict__['_hip'] = None
-        return super()._load_from_state_dict(*args, **kwargs)
+    _native_cache = ('_hip',)
 
     def _packed(self):
         p = self.__dict__.get('_hip')
@@ -235,12 +230,6 @@ class TemporalFusionMultiFrame(nn.Module):
         self.before_fusion_layer = BeforeFusionLayer(channels)
         self.t_fuse_mid = TemporalFusionMultiFrameMiddle3x3Seq(channels, seqs=seqs)
         self.deform_fusion_layer = TemporalFusionDeformMiddle(channels)
-
-    def train(self, mode=True):
-        for m in self.modules():
-            if isinstance(m, ConvModule3d):
-                m.__dict__['_hip3'] = None
-        return super().train(mode)
 
     def hip_ok(self, x):
         c = self.t_final.conv.out_channels
