@@ -374,6 +374,14 @@ int veon_image_resize_bilinear(const void *in_padded, void *out_padded, int B,
  * act 0 none / 1 ReLU / 2 sigmoid (the tail of DPTHead.output_conv2, dpt.py). */
 int veon_image_dot(const void *in_padded, const float *w, float bias, float *out,
                    int B, int C, int Y, int X, int act, void *stream);
+/* LayerNorm over the channels of every pixel of a padded channels-last bf16 image:
+ * the nn.LayerNorm calls of ConvBlock.forward (highres_side_adaptor.py:31-52) with
+ * their permute / reshape pairs.  out_tokens_f32 = 0: out is a padded bf16 image of
+ * the same shape, halo written as zeros (input of the next 3x3 conv); 1: out is the
+ * compact fp32 token tensor (B, Y*X, C).  C % 8 == 0, C <= 1024. */
+int veon_image_layernorm_bf16(const void *in_padded, const float *gamma,
+                              const float *beta, void *out, int out_tokens_f32, int B,
+                              int C, int Y, int X, float eps, void *stream);
 /* ---- temporal path, csrc/temporal.hip ---------------------
  * Sampling + attention core of TemporalDeformable.forward
  * (mmdet3d/models/semantic_net/side_adapter/align_net_occ3d.py:138-196), replacing

@@ -456,3 +456,24 @@ def test_cat_fusion_lift_mfma_path_feeds_the_lift_without_a_copy():
     assert got.permute(0, 2, 3, 1).is_contiguous()
     rel = ((got.float() - want).norm() / want.norm()).item()
     assert rel < 1.5e-2, rel
+
+
+@pytest.mark.parametrize('C,Y,X', [(384, 5, 7), (64, 3, 4), (1024, 2, 3), (520, 4, 4)])
+def test_image_layernorm_matches_torch(C, Y, X):
+    """LayerNorm over the channels of a padded image: padded bf16 result (zero
+    halo) and compact fp32 tokens, against F.layer_norm on the same bf16 rows."""
+    g = torch.Generator().manual_seed(C)
+    B = 2
+    x = _bf(torch.randn(B, C, Y, X, generator=g) * 2 + 0.5).to(DEV)
+    gamma = (torch.rand(C, generator=g) + 0.5).to(DEV)
+    beta = torch.randn(C, generator=g).to(DEV)
+    img = conv3d_ops.pack_image(x)
+    want = F.layer_norm(x.permute(0, 2, 3, 1), (C,), gamma, beta, 1e-5)     # (B,Y,X,C)
+    tok = conv3d_ops.image_layernorm(img, gamma, beta, 1e-5, tokens=True)
+    torch.testing.assert_close(tok, want.reshape(B, Y * X, C), rtol=1e-5, atol=1e-5)
+    out = conv3d_ops.image_layernorm(img, gamma, beta, 1e-5)
+    grid = out.rows.view(B, Y + 2, X + 2, C).float()
+    _close(grid[:, 1:-1, 1:-1], want)
+    halo = grid.clone()
+    halo[:, 1:-1, 1:-1] = 0
+    assert float(halo.abs().sum()) == 0.0

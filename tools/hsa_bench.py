@@ -26,7 +26,7 @@ def main():
             with torch.autocast('cuda', dtype=torch.bfloat16):
                 t16 = timeit(lambda: net(img, clip), 5)
             net.set_conv_dtype(torch.bfloat16)
-            tm = timeit(lambda: net(img, clip), 5)
+            tm = timeit(lambda: net(img, clip), 20)
             blk = net.hsa_net_body[1].ff
             x = torch.randn(6, toks, 384, device=dev)
             tb = timeit(lambda: blk(x, (size[0] // 8, size[1] // 8)), 10)

@@ -65,6 +65,7 @@ _SIGNATURES = {
     'veon_image_dot': (_ci, [_vp, _vp, _cf, _vp] + [_ci] * 5 + [_vp]),
     'veon_image_pack_bf16': (_ci, [_vp, _ci, _vp] + [_ci] * 4 + [_vp]),
     'veon_image_unpack': (_ci, [_vp, _vp, _ci] + [_ci] * 4 + [_vp]),
+    'veon_image_layernorm_bf16': (_ci, [_vp] * 4 + [_ci] * 5 + [_cf, _vp]),
     'veon_deform_attention_bf16': (_ci, [_vp] * 4 + [_ci] * 8 + [_vp]),
     'veon_volume_warp_bf16': (_ci, [_vp] * 3 + [_ci] * 5 + [_vp]),
     'veon_warp_affine': (_ci, [_vp, _vp, _ci, _vp, _vp, _vp, _ci, _vp]),

@@ -348,6 +348,83 @@ __global__ __launch_bounds__(256) void k_image_dot(
   out[idx] = acc;
 }
 
+// LayerNorm over the channels of every pixel of a padded channels-last bf16 image
+// (the LayerNorms between the 3x3 convs of the HSA network's ConvBlock,
+// highres_side_adaptor.py:31-52, which the reference reaches through two
+// permutes).  One wave per padded row, up to two 16-byte chunks per lane
+// (C <= 1024), statistics in fp32 (mean, then the centred sum of squares).
+// TOKENS = false: -> padded bf16 image, halo rows written as zeros (ready for the
+// next conv); TOKENS = true: -> compact fp32 tokens (B, Y*X, C), halo skipped.
+template <bool TOKENS>
+__global__ __launch_bounds__(256) void k_image_layernorm(
+    const bf16_t* __restrict__ in, const float* __restrict__ gamma,
+    const float* __restrict__ beta, void* __restrict__ out, int B, int Y, int X, int C,
+    float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int Yp = Y + 2, Xp = X + 2;
+  if (m >= (int64_t)B * Yp * Xp) return;
+  const int x = (int)(m % Xp), y = (int)((m / Xp) % Yp), b = (int)(m / ((int64_t)Xp * Yp));
+  const bool interior = x >= 1 && x <= X && y >= 1 && y <= Y;
+  const int nchunk = C / 8;
+  const bool has0 = lane < nchunk, has1 = lane + 64 < nchunk;
+  if (!interior) {
+    if (!TOKENS) {
+      const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+      bf16_t* o = static_cast<bf16_t*>(out) + m * C;
+      if (has0) *reinterpret_cast<bf16x8*>(o + lane * 8) = zero;
+      if (has1) *reinterpret_cast<bf16x8*>(o + (lane + 64) * 8) = zero;
+    }
+    return;
+  }
+  float v[16];
+  float sum = 0.f;
+  {
+    const bf16_t* p = in + m * C;
+    bf16x8 c0 = {0, 0, 0, 0, 0, 0, 0, 0}, c1 = c0;
+    if (has0) c0 = *reinterpret_cast<const bf16x8*>(p + lane * 8);
+    if (has1) c1 = *reinterpret_cast<const bf16x8*>(p + (lane + 64) * 8);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      v[k] = bf2f((bf16_t)c0[k]);
+      v[8 + k] = bf2f((bf16_t)c1[k]);
+      sum += v[k] + v[8 + k];
+    }
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d);
+  const float mean = sum / C;
+  float sq = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const float a = has0 ? v[k] - mean : 0.f, c = has1 ? v[8 + k] - mean : 0.f;
+    sq += a * a + c * c;
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) sq += __shfl_xor(sq, d);
+  const float rstd = rsqrtf(sq / C + eps);
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    if (!(h == 0 ? has0 : has1)) continue;
+    const int c0 = (lane + 64 * h) * 8;
+    float r[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      r[k] = (v[8 * h + k] - mean) * rstd * gamma[c0 + k] + beta[c0 + k];
+    if (TOKENS) {
+      float* o = static_cast<float*>(out) +
+                 (((int64_t)b * Y + (y - 1)) * X + (x - 1)) * C + c0;
+      *reinterpret_cast<float4*>(o) = float4{r[0], r[1], r[2], r[3]};
+      *reinterpret_cast<float4*>(o + 4) = float4{r[4], r[5], r[6], r[7]};
+    } else {
+      bf16x8 o8;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) o8[k] = (short)f2bf(r[k]);
+      *reinterpret_cast<bf16x8*>(static_cast<bf16_t*>(out) + m * C + c0) = o8;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -554,6 +631,27 @@ int veon_image_dot(const void* in_padded, const float* w, float bias, float* out
                        bias, out, B, Y, X, act);
   else
     return VEON_ERR_BAD_ARG;
+  return launch_status();
+}
+
+int veon_image_layernorm_bf16(const void* in_padded, const float* gamma,
+                              const float* beta, void* out, int out_tokens_f32, int B,
+                              int C, int Y, int X, float eps, void* stream) {
+  if (B <= 0 || Y <= 0 || X <= 0 || C <= 0 || C % 8 != 0 || C > 1024 || !in_padded ||
+      !gamma || !beta || !out || in_padded == out)
+    return VEON_ERR_BAD_ARG;
+  if (!al16(in_padded) || !al16(out)) return VEON_ERR_BAD_ARG;
+  const int64_t M = (int64_t)B * (Y + 2) * (X + 2);
+  const int64_t blocks = (M + 3) / 4;
+  if (blocks > 0x7fffffffLL) return VEON_ERR_BAD_ARG;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const bf16_t* I = static_cast<const bf16_t*>(in_padded);
+  if (out_tokens_f32)
+    hipLaunchKernelGGL(k_image_layernorm<true>, dim3((unsigned)blocks), dim3(256), 0, s, I,
+                       gamma, beta, out, B, Y, X, C, eps);
+  else
+    hipLaunchKernelGGL(k_image_layernorm<false>, dim3((unsigned)blocks), dim3(256), 0, s, I,
+                       gamma, beta, out, B, Y, X, C, eps);
   return launch_status();
 }
 

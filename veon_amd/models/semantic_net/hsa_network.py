@@ -97,8 +97,8 @@ class ConvBlock(NativeCacheMixin, nn.Module):
             st['w'] = [(conv3d_ops.pack_weight2d(c.weight),
                         c.bias.detach().float().contiguous())
                        for c in (self.conv1, self.conv2)]
-            st['ln'] = [(ln.weight.detach().to(torch.bfloat16),
-                         ln.bias.detach().to(torch.bfloat16)) for ln in (self.ln1, self.ln2)]
+            st['ln'] = [(ln.weight.detach().float().contiguous(),
+                         ln.bias.detach().float().contiguous()) for ln in (self.ln1, self.ln2)]
         key = (B, H, W)
         if key not in st:
             dev = x.device
@@ -113,11 +113,12 @@ class ConvBlock(NativeCacheMixin, nn.Module):
         # tokens are channels-last already: one strided copy into the interior
         interior(a).copy_(x.view(B, H, W, self.dim))
         conv3d_ops.conv2d_k3(a, w1, None, b1, act='gelu', out=b)
-        # LayerNorm over the channels of every pixel: bf16 in / out, fp32 inside
-        interior(c).copy_(F.layer_norm(interior(b), (self.h_dim,), g1, e1, self.ln1.eps))
+        # LayerNorm over the channels of every pixel on the padded rows (fp32
+        # statistics): the first writes the next conv's padded input, the second
+        # the fp32 tokens
+        conv3d_ops.image_layernorm(b, g1, e1, self.ln1.eps, out=c)
         conv3d_ops.conv2d_k3(c, w2, None, b2, out=d)
-        y = F.layer_norm(interior(d), (self.out_dim,), g2, e2, self.ln2.eps)
-        return y.float().reshape(B, L, self.out_dim)
+        return conv3d_ops.image_layernorm(d, g2, e2, self.ln2.eps, tokens=True)
 
     def forward(self, x, size=(1, 1)):
         B, L, dim = x.shape
