@@ -33,6 +33,25 @@ def main():
         t_issue = time.perf_counter() - t0
         torch.cuda.synchronize()
         t_all = time.perf_counter() - t0
+        if os.environ.get('CAPTURE') == '1':
+            # Stream capture records the launches without running them: the time to
+            # capture one forward is the pure host cost of issuing it (the graph is
+            # dropped, never replayed).
+            net.two_streams = False
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                net(images, geom)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            t1 = time.perf_counter()
+            with torch.cuda.graph(g):
+                net(images, geom)
+            t_cap = time.perf_counter() - t1
+            del g
+            print('host cost of issuing one forward (stream capture, nothing executes): '
+                  '%.2f ms' % (t_cap * 1e3))
     print('%d forwards (+3 warm-up): wall %.2f ms per step, host issue time %.2f ms per step'
           % (n, t_all / n * 1e3, t_issue / n * 1e3))
 

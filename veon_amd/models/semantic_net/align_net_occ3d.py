@@ -79,7 +79,9 @@ class AlignNetOcc3D(nn.Module):
         sensor2egos = sensor2egos.view(-1, self.num_frame, N, 4, 4)
         ego2globals = ego2globals.view(-1, self.num_frame, N, 4, 4)
         keyego2global = ego2globals[:, 0, 0, ...].unsqueeze(1).unsqueeze(1)
-        global2keyego = torch.inverse(keyego2global.double())
+        # same LU routine as torch.inverse, minus its host-side check of `info`
+        # (a device->host sync in front of the whole decoder)
+        global2keyego = torch.linalg.inv_ex(keyego2global.double(), check_errors=False)[0]
         sensor2keyegos = (global2keyego @ ego2globals.double()
                           @ sensor2egos.double()).float()
         extra = [sensor2keyegos, ego2globals,
