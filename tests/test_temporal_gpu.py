@@ -29,7 +29,8 @@ def _close(got, want, k=4e-3):
 
 
 @pytest.mark.parametrize('B,C,heads,Z,Y,X', [(2, 256, 4, 3, 9, 11), (1, 128, 4, 2, 5, 7),
-                                            (1, 256, 4, 1, 1, 1), (1, 64, 2, 8, 13, 10)])
+                                            (1, 256, 4, 1, 1, 1), (1, 64, 2, 8, 13, 10),
+                                            (2, 256, 8, 2, 5, 6), (1, 32, 1, 3, 4, 5)])
 def test_deform_attention_matches_torch(B, C, heads, Z, Y, X):
     g = torch.Generator().manual_seed(C + X)
     kv = _bf(torch.randn(B, 2 * C, Z, Y, X, generator=g)).to(DEV)

@@ -19,10 +19,20 @@ def main():
     n = int(os.environ.get('N', 20))
     dev, size = 'cuda:0', (256, 704)
     torch.manual_seed(0)
-    net = VeonOccupancyPath(input_size=size, encoder='vitb').to(dev).eval()
+    temporal = os.environ.get('TEMPORAL') == '1'
+    net = VeonOccupancyPath(input_size=size, encoder='vitb',
+                            num_temporal=2 if temporal else 1).to(dev).eval()
     net.two_streams = os.environ.get('TWO_STREAMS', '0') == '1'
     geom = [t.to(dev) for t in synthetic.rig_inputs(synthetic.make_rig(1, 6, size))]
     images = torch.randn(1, 6, 3, *size, device=dev)
+    if temporal:   # streaming form: kept past volume, warp + fusion every step
+        eye = torch.eye(4, device=dev)[None, None]
+        move = eye.clone()
+        move[0, 0, :3, 3] = torch.tensor([1.5, 0.2, 0.01], device=dev)
+        with torch.no_grad():
+            kept = net.lift_frame(torch.randn_like(images), geom)
+        plain = net.forward
+        net.forward = lambda im, gm: plain(im, gm, [net.align(kept, [eye, move])])
     with torch.no_grad():
         for _ in range(3):
             net(images, geom)
