@@ -238,6 +238,24 @@ def main():
                       file=sys.stderr)
                 graph = None
         run = graph.replay if graph is not None else step
+        launch_probe = None
+        if graph is not None:
+            # A replay of this two-kernel graph costs more on the GPU front end than
+            # the two plain launches do on the host on some boxes (and less on
+            # others): measure both briefly, run the timed steps with the faster.
+            def probe(fn, n=40):
+                for _ in range(5):
+                    fn()
+                torch.cuda.synchronize()
+                t = time.perf_counter()
+                for _ in range(n):
+                    fn()
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t) / n * 1e6
+            launch_probe = {'hipGraph_us': round(probe(graph.replay), 2),
+                            'eager_us': round(probe(step), 2)}
+            if launch_probe['eager_us'] < launch_probe['hipGraph_us']:
+                run, graph = step, None
 
         for _ in range(args.warmup):
             run()
@@ -347,6 +365,7 @@ def main():
                            D, C, X, Y, Z),
             'points_kept': p_kept, 'intervals': n_int,
             'launch': 'hipGraph' if graph is not None else 'eager',
+            'launch_probe_us_per_step': launch_probe,
             'output_volume': ('persistent, best-placed of %d allocations (kernel %.1f us vs '
                               'median %.1f us; veon_amd/placement.py)' % (
                                   vt.placement_info['candidates'],
