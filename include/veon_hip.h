@@ -156,6 +156,20 @@ int veon_bev_pool_v2_fwd_fused_ex(int c, int n_intervals, int batch,
                                   const int *interval_starts,
                                   const int *interval_lengths, const int *plan,
                                   float *out, int out_layout, void *stream);
+/* As veon_bev_pool_v2_fwd_fused_ex with the (B,C,Z,Y,X) layout, but the channel
+ * planes of `out` are `plane_stride` floats apart (>= voxels_per_batch): out is a
+ * (B, C, plane_stride) buffer whose first voxels_per_batch floats of every plane
+ * are written.  For consumers that take a strided view, and for
+ * tools/stride_probe.py (placement sensitivity of the plane streams). */
+int veon_bev_pool_v2_fwd_fused_strided(int c, int n_intervals, int batch,
+                                       int64_t voxels_per_batch, const float *depth,
+                                       const void *feat, int feat_dtype,
+                                       const int *ranks_depth, const int *ranks_feat,
+                                       const int *ranks_bev,
+                                       const int *interval_starts,
+                                       const int *interval_lengths, const int *plan,
+                                       float *out, int64_t plane_stride,
+                                       void *stream);
 int veon_bev_pool_v2_fwd_maxpool_ex(int c, int n_intervals, int batch, int Z,
                                     int Y, int X, int dz, int dy, int dx,
                                     const float *depth, const void *feat,
@@ -374,6 +388,14 @@ int veon_image_resize_bilinear(const void *in_padded, void *out_padded, int B,
  * act 0 none / 1 ReLU / 2 sigmoid (the tail of DPTHead.output_conv2, dpt.py). */
 int veon_image_dot(const void *in_padded, const float *w, float bias, float *out,
                    int B, int C, int Y, int X, int act, void *stream);
+/* Physically contiguous device memory (hipExtMallocWithFlags +
+ * hipDeviceMallocContiguous) for the lift's output volume, whose write pattern
+ * (C planes 4*Z*Y*X bytes apart per workgroup) is sensitive to the page-table
+ * fragment size; VEON_ERR_LAUNCH when the driver cannot provide it (the caller
+ * then keeps an ordinary allocation).  No reference counterpart: the reference
+ * lets torch.zeros allocate the volume (bev_pool.py:17-19). */
+int veon_alloc_contiguous(void **ptr, int64_t bytes);
+int veon_free_device(void *ptr);
 /* LayerNorm over the channels of every pixel of a padded channels-last bf16 image:
  * the nn.LayerNorm calls of ConvBlock.forward (highres_side_adaptor.py:31-52) with
  * their permute / reshape pairs.  out_tokens_f32 = 0: out is a padded bf16 image of

@@ -426,3 +426,66 @@ def test_half_feat_with_grad_takes_fp32_autograd_path():
     assert d.grad is not None and torch.isfinite(d.grad).all()
     want = _oracle_out(depth, f.detach().float().cpu().numpy(), ranks, shape)
     assert np.array_equal(out.detach().cpu().numpy(), want.transpose(0, 4, 1, 2, 3))
+
+
+def test_contiguous_volume_allocation_is_a_usable_tensor():
+    """placement.contiguous_tensor: physically contiguous VRAM wrapped as a torch
+    tensor (or None when the driver refuses); the pool writes into it like into
+    any other buffer, and the block is released with the tensor."""
+    import gc
+    import torch
+    from veon_amd import placement
+    t = placement.contiguous_tensor((3, 5, 7), torch.float32, torch.device('cuda:0'))
+    if t is None:
+        pytest.skip('driver gave no contiguous block')
+    assert t.is_cuda and t.shape == (3, 5, 7) and t.is_contiguous()
+    t.fill_(2.5)
+    assert float(t.sum()) == 2.5 * 105
+    u = t.view(-1)[10:20]
+    del t
+    gc.collect()
+    u += 1                      # the view keeps the block alive
+    assert float(u.sum()) == 35.0
+    del u
+    gc.collect()
+    torch.cuda.synchronize()
+
+
+def test_fused_pool_into_padded_planes_equals_contiguous():
+    """veon_bev_pool_v2_fwd_fused_strided: channel planes `plane_stride` floats
+    apart hold exactly the contiguous (B,C,Z,Y,X) result; the padding between the
+    planes is not touched; a stride below the plane size is refused."""
+    import ctypes
+    import torch
+    from tools._inputs import lift_case
+    from veon_amd import _lib, synthetic
+    from veon_amd.ops.bev_pool_v2 import bev_pool as bp
+    dev = 'cuda:0'
+    C = 16
+    grid = {'x': [-10.0, 10.0, 1.0], 'y': [-10.0, 10.0, 1.0], 'z': [-1.0, 3.0, 1.0],
+            'depth': [1.0, 13.0, 1.0]}
+    case = lift_case(grid, (64, 176), 2, C, dev)
+    depth, feat = case['depth'], case['feat_nhwc']
+    rb, rd, rf, st, ln = (case[k] for k in ('rb', 'rd', 'rf', 'st', 'ln'))
+    X, Y, Z = case['gsize']
+    vpb = X * Y * Z
+    bp.mark_sorted(st, int(rb[0]), int(rb[-1]))
+    plan = bp.build_plan(rb, st, 1, vpb)
+    L = _lib.lib()
+    s = _lib.stream_ptr(torch.device(dev))
+
+    def run(out, stride):
+        return L.veon_bev_pool_v2_fwd_fused_strided(
+            C, st.numel(), 1, vpb, _lib.ptr(depth), _lib.ptr(feat), _lib.FEAT_F32,
+            _lib.ptr(rd), _lib.ptr(rf), _lib.ptr(rb), _lib.ptr(st), _lib.ptr(ln),
+            _lib.ptr(plan), _lib.ptr(out), stride, s)
+    want = torch.empty(C, vpb, device=dev)
+    assert run(want, vpb) == 0
+    pad = 192
+    got = torch.full((C, vpb + pad), -7.0, device=dev)
+    assert run(got, vpb + pad) == 0
+    torch.cuda.synchronize()
+    assert float(want.abs().sum()) > 0
+    assert torch.equal(got[:, :vpb], want)
+    assert bool((got[:, vpb:] == -7.0).all())
+    assert run(got, vpb - 1) != 0

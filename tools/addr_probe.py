@@ -61,6 +61,15 @@ def main():
         b = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         print('re-allocated: same address %s, %6.2f us' % (b.data_ptr() == ptr, timeit(run(b.data_ptr()), 20)))
         keep.append(b)
+    # a physically contiguous block (hipDeviceMallocContiguous): largest page-table
+    # fragments the driver can map -- is the bimodality a TLB effect?
+    from veon_amd import placement
+    cb = placement.contiguous_tensor((nbytes,), torch.uint8, torch.device(dev))
+    if cb is None:
+        print('contiguous block: driver gave none')
+    else:
+        print('contiguous block @%#x  %6.2f %6.2f us' % (cb.data_ptr(), timeit(run(cb.data_ptr()), 20),
+                                                        timeit(run(cb.data_ptr()), 20)))
     arena = keep[0]
     # output of the product wrapper (allocator-reused block), as kbench measures it
     shape = (1, Z, Y, X, C)

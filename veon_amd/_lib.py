@@ -42,6 +42,7 @@ _SIGNATURES = {
     'veon_bev_pool_v2_fwd': (_ci, [_ci, _ci] + [_vp] * 8 + [_vp]),
     'veon_bev_pool_v2_bwd': (_ci, [_ci, _ci] + [_vp] * 10 + [_vp]),
     'veon_bev_pool_v2_fwd_fused': (_ci, [_ci, _ci, _ci, _i64] + [_vp] * 9 + [_ci, _vp]),
+    'veon_bev_pool_v2_fwd_fused_strided': (_ci, [_ci, _ci, _ci, _i64, _vp, _vp, _ci] + [_vp] * 7 + [_i64, _vp]),
     'veon_bev_pool_v2_fwd_fused_ex': (_ci, [_ci, _ci, _ci, _i64, _vp, _vp, _ci] + [_vp] * 7 + [_ci, _vp]),
     'veon_bev_pool_v2_fwd_maxpool_ex': (_ci, [_ci] * 9 + [_vp, _vp, _ci] + [_vp] * 7 + [_vp]),
     'veon_bev_pool_v2_fwd_maxpool_padded': (_ci, [_ci] * 9 + [_vp, _vp, _ci] + [_vp] * 7 + [_vp]),
@@ -65,6 +66,8 @@ _SIGNATURES = {
     'veon_image_dot': (_ci, [_vp, _vp, _cf, _vp] + [_ci] * 5 + [_vp]),
     'veon_image_pack_bf16': (_ci, [_vp, _ci, _vp] + [_ci] * 4 + [_vp]),
     'veon_image_unpack': (_ci, [_vp, _vp, _ci] + [_ci] * 4 + [_vp]),
+    'veon_alloc_contiguous': (_ci, [_vp, _i64]),
+    'veon_free_device': (_ci, [_vp]),
     'veon_image_layernorm_bf16': (_ci, [_vp] * 4 + [_ci] * 5 + [_cf, _vp]),
     'veon_deform_attention_bf16': (_ci, [_vp] * 4 + [_ci] * 8 + [_vp]),
     'veon_volume_warp_bf16': (_ci, [_vp] * 3 + [_ci] * 5 + [_vp]),

@@ -347,7 +347,9 @@ constexpr int kPmax = 1024;  // points staged per window (8 B each)
 template <int VEC, int CAP, typename FT>
 __global__ __launch_bounds__(kBlock) void k_pool_fused_cf(
     PoolArgs a, const int4* __restrict__ plan, int c, int cs, int64_t vpb,
-    int64_t tiles_per_batch, float* __restrict__ out) {
+    int64_t tiles_per_batch, float* __restrict__ out, int64_t ostride) {
+  // ostride: distance between channel planes of `out` in floats (>= vpb; vpb for
+  // the contiguous (B,C,Z,Y,X) tensor the reference returns)
   extern __shared__ float lds[];
   constexpr int LDC = CAP + 1;
   constexpr int UNROLL = 8;  // rows in flight per lane
@@ -366,7 +368,7 @@ __global__ __launch_bounds__(kBlock) void k_pool_fused_cf(
   const int c0 = blockIdx.y * cs;
   const int nch = (c - c0) < cs ? (c - c0) : cs;
   const TileInfo ti = tile_info(t, tiles_per_batch, vpb);
-  float* obase = out + ((int64_t)ti.b * c + c0) * vpb + ti.vox0;
+  float* obase = out + ((int64_t)ti.b * c + c0) * ostride + ti.vox0;
 
   const int4 pl = plan[t];
   const int i0 = pl.x, cnt = pl.y, p0 = pl.z, npts = pl.w;
@@ -374,7 +376,7 @@ __global__ __launch_bounds__(kBlock) void k_pool_fused_cf(
   if (cnt == 0) {  // empty tile: pure streaming zero fill
     if (lane < ti.nvox)
       for (int cc = w; cc < nch; cc += NW)
-        __builtin_nontemporal_store(0.f, obase + (int64_t)cc * vpb + lane);
+        __builtin_nontemporal_store(0.f, obase + (int64_t)cc * ostride + lane);
     return;
   }
   // level 2: everything that depends only on the plan entry
@@ -483,11 +485,11 @@ __global__ __launch_bounds__(kBlock) void k_pool_fused_cf(
 #pragma unroll
           for (int u = 0; u < SB; ++u)
             __builtin_nontemporal_store(vals[u],
-                                        op + (int64_t)(cc + NW * u) * vpb);
+                                        op + (int64_t)(cc + NW * u) * ostride);
         }
         for (; cc < nch; cc += NW)
           __builtin_nontemporal_store(occupied ? tile[cc * LDC + col] : 0.f,
-                                      op + (int64_t)cc * vpb);
+                                      op + (int64_t)cc * ostride);
       }
     } else {
       // half tile (32 voxels): one wave instruction = 2 channels x 128 B
@@ -497,7 +499,7 @@ __global__ __launch_bounds__(kBlock) void k_pool_fused_cf(
       if (v < ti.nvox)
         for (int cc = 2 * w + (lane >> 5); cc < nch; cc += 2 * NW)
           __builtin_nontemporal_store(occupied ? tile[cc * LDC + col] : 0.f,
-                                      obase + (int64_t)cc * vpb + v);
+                                      obase + (int64_t)cc * ostride + v);
       if (pass == 0) __syncthreads();  // the tile is reused by the second half
     }
   }
@@ -905,16 +907,18 @@ int veon_bev_pool_v2_fwd_maxpool(int c, int n_intervals, int batch, int Z, int Y
       row_first, out, stream);
 }
 
-int veon_bev_pool_v2_fwd_fused_ex(int c, int n_intervals, int batch,
-                                  int64_t voxels_per_batch, const float* depth,
-                                  const void* feat, int feat_dtype,
-                                  const int* ranks_depth, const int* ranks_feat,
-                                  const int* ranks_bev,
-                                  const int* interval_starts,
-                                  const int* interval_lengths, const int* plan,
-                                  float* out, int out_layout, void* stream) {
+static int fused_impl(int c, int n_intervals, int batch, int64_t voxels_per_batch,
+                      const float* depth, const void* feat, int feat_dtype,
+                      const int* ranks_depth, const int* ranks_feat,
+                      const int* ranks_bev, const int* interval_starts,
+                      const int* interval_lengths, const int* plan, float* out,
+                      int out_layout, int64_t plane_stride, void* stream) {
   if (c <= 0 || n_intervals < 0 || batch <= 0 || voxels_per_batch <= 0 ||
       !out || !plan)
+    return VEON_ERR_BAD_ARG;
+  if (plane_stride == 0) plane_stride = voxels_per_batch;
+  if (plane_stride < voxels_per_batch ||
+      (plane_stride != voxels_per_batch && out_layout != VEON_LAYOUT_BCZYX))
     return VEON_ERR_BAD_ARG;
   if (out_layout != VEON_LAYOUT_BZYXC && out_layout != VEON_LAYOUT_BCZYX)
     return VEON_ERR_BAD_ARG;
@@ -962,7 +966,8 @@ int veon_bev_pool_v2_fwd_fused_ex(int c, int n_intervals, int batch,
   const dim3 grid((unsigned)n_tiles, (unsigned)slabs);
 #define VEON_LAUNCH_CF(VEC, CAP, FT)                                          \
   hipLaunchKernelGGL((k_pool_fused_cf<VEC, CAP, FT>), grid, dim3(kBlock), lds, \
-                     s, a, plan4, c, cs, voxels_per_batch, tiles_per_batch, out)
+                     s, a, plan4, c, cs, voxels_per_batch, tiles_per_batch, out,   \
+                     plane_stride)
 #define VEON_LAUNCH_CF2(VEC, FT) \
   do { if (dense) VEON_LAUNCH_CF(VEC, 64, FT); else VEON_LAUNCH_CF(VEC, 32, FT); } while (0)
   if (feat_dtype == VEON_FEAT_F32) {
@@ -981,6 +986,34 @@ int veon_bev_pool_v2_fwd_fused_ex(int c, int n_intervals, int batch,
 #undef VEON_LAUNCH_CF2
 #undef VEON_LAUNCH_CF
   return launch_status();
+}
+
+int veon_bev_pool_v2_fwd_fused_ex(int c, int n_intervals, int batch,
+                                  int64_t voxels_per_batch, const float* depth,
+                                  const void* feat, int feat_dtype,
+                                  const int* ranks_depth, const int* ranks_feat,
+                                  const int* ranks_bev,
+                                  const int* interval_starts,
+                                  const int* interval_lengths, const int* plan,
+                                  float* out, int out_layout, void* stream) {
+  return fused_impl(c, n_intervals, batch, voxels_per_batch, depth, feat, feat_dtype,
+                    ranks_depth, ranks_feat, ranks_bev, interval_starts,
+                    interval_lengths, plan, out, out_layout, 0, stream);
+}
+
+int veon_bev_pool_v2_fwd_fused_strided(int c, int n_intervals, int batch,
+                                       int64_t voxels_per_batch, const float* depth,
+                                       const void* feat, int feat_dtype,
+                                       const int* ranks_depth, const int* ranks_feat,
+                                       const int* ranks_bev,
+                                       const int* interval_starts,
+                                       const int* interval_lengths, const int* plan,
+                                       float* out, int64_t plane_stride,
+                                       void* stream) {
+  return fused_impl(c, n_intervals, batch, voxels_per_batch, depth, feat, feat_dtype,
+                    ranks_depth, ranks_feat, ranks_bev, interval_starts,
+                    interval_lengths, plan, out, VEON_LAYOUT_BCZYX, plane_stride,
+                    stream);
 }
 
 int veon_bev_pool_v2_fwd_fused(int c, int n_intervals, int batch,

@@ -5,16 +5,68 @@ The fused pool kernel writes 64-voxel rows of all C channel planes of the
 apart (2.56 MB at 200x200x16) per workgroup.  On MI355X the very same launch
 runs ~34 us into some 205 MB allocations and ~41 us into others (bimodal,
 stable per allocation, independent of the virtual address, neighbouring
-allocations tend to agree; a linear fill is insensitive) -- consistent with the
-size of the page-table fragments the driver could give the allocation
-(physical contiguity), which decides how many TLB entries the C planes need.
-See DESIGN.md section 4 and tools/addr_probe.py.
+allocations tend to agree; a linear fill is insensitive).  It is NOT the size of
+the page-table fragments: a physically contiguous block
+(``contiguous_tensor``: hipDeviceMallocContiguous, the largest fragments the
+driver can map) is among the slowest placements measured (48.2 us in the probe
+against 43.1 us for the best of 17 ordinary allocations).  What is left is how
+the C plane streams, 2.56 MB apart, fall onto HBM channels / banks: a contiguous
+block maps them the most regularly.  See DESIGN.md section 4 and
+tools/addr_probe.py.
 
 A consumer that keeps ONE output buffer alive across calls (a hipGraph replay
 does so anyway) can therefore pick a well-placed one once: ``best_placed``
 times a probe on a handful of candidate allocations and keeps the fastest.
 """
+import ctypes
+
 import torch
+
+_TYPESTR = {torch.float32: '<f4', torch.bfloat16: None, torch.float16: '<f2',
+            torch.uint8: '|u1', torch.int32: '<i4'}
+
+
+class _ContiguousBlock:
+    """Owner of one ``veon_alloc_contiguous`` block, exposed to torch through
+    ``__cuda_array_interface__`` (the tensor made from it keeps this object, and
+    so the memory, alive)."""
+
+    def __init__(self, shape, dtype, device):
+        from . import _lib
+        self._lib = _lib
+        self.nbytes = torch.empty((), dtype=dtype).element_size()
+        for d in shape:
+            self.nbytes *= int(d)
+        p = ctypes.c_void_p(0)
+        with torch.cuda.device(device):
+            st = _lib.lib().veon_alloc_contiguous(ctypes.byref(p), self.nbytes)
+        if st != 0 or not p.value:
+            raise MemoryError('no physically contiguous block of %d bytes' % self.nbytes)
+        self.ptr, self.device = p.value, device
+        self.__cuda_array_interface__ = {
+            'shape': tuple(int(d) for d in shape), 'typestr': _TYPESTR[dtype],
+            'data': (self.ptr, False), 'version': 2, 'strides': None}
+
+    def __del__(self):
+        ptr, self.ptr = getattr(self, 'ptr', None), None
+        if ptr:
+            try:
+                with torch.cuda.device(self.device):
+                    self._lib.lib().veon_free_device(ctypes.c_void_p(ptr))
+            except Exception:   # interpreter shutdown
+                pass
+
+
+def contiguous_tensor(shape, dtype=torch.float32, device=None):
+    """A tensor on physically contiguous VRAM (hipDeviceMallocContiguous), or None
+    when the driver cannot provide one."""
+    if _TYPESTR.get(dtype) is None:
+        return None
+    try:
+        block = _ContiguousBlock(shape, dtype, device)
+    except (MemoryError, AttributeError, OSError):
+        return None
+    return torch.as_tensor(block, device=device)
 
 
 def _time(fn, out, iters):
