@@ -395,6 +395,8 @@ int veon_image_dot(const void *in_padded, const float *w, float bias, float *out
  * then keeps an ordinary allocation).  No reference counterpart: the reference
  * lets torch.zeros allocate the volume (bev_pool.py:17-19). */
 int veon_alloc_contiguous(void **ptr, int64_t bytes);
+/* the same with any hipExtMallocWithFlags flag (probe tool) */
+int veon_alloc_device_flags(void **ptr, int64_t bytes, unsigned flags);
 int veon_free_device(void *ptr);
 /* LayerNorm over the channels of every pixel of a padded channels-last bf16 image:
  * the nn.LayerNorm calls of ConvBlock.forward (highres_side_adaptor.py:31-52) with

@@ -64,13 +64,18 @@ def main():
     # a physically contiguous block (hipDeviceMallocContiguous): largest page-table
     # fragments the driver can map -- is the bimodality a TLB effect?
     from veon_amd import placement
-    cb = placement.contiguous_tensor((nbytes,), torch.uint8, torch.device(dev))
-    if cb is None:
-        print('contiguous block: driver gave none')
-    else:
-        print('contiguous block @%#x  %6.2f %6.2f us' % (cb.data_ptr(), timeit(run(cb.data_ptr()), 20),
-                                                        timeit(run(cb.data_ptr()), 20)))
-    arena = keep[0]
+    for name, flags in (('contiguous', None), ('default flag 0', 0), ('fine-grained', 1),
+                        ('uncached', 3)):
+        for rep in range(3):
+            cb = placement.contiguous_tensor((nbytes,), torch.uint8, torch.device(dev), flags)
+            if cb is None:
+                print('%s block: driver gave none' % name)
+                break
+            print('%-16s @%#x  %6.2f %6.2f us' % (name, cb.data_ptr(),
+                                                 timeit(run(cb.data_ptr()), 20),
+                                                 timeit(run(cb.data_ptr()), 20)))
+            keep.append(cb)
+    arena = next(b for b in keep if b is not None)
     # output of the product wrapper (allocator-reused block), as kbench measures it
     shape = (1, Z, Y, X, C)
     f = lambda: bp._fused_forward(depth, feat, rd, rf, rb, st, ln, shape, _lib.LAYOUT_BCZYX)

@@ -21,6 +21,19 @@ int veon_alloc_contiguous(void** ptr, int64_t bytes) {
   return VEON_OK;
 }
 
+int veon_alloc_device_flags(void** ptr, int64_t bytes, unsigned flags) {
+  // any hipExtMallocWithFlags flag (hipDeviceMallocDefault 0, Finegrained 1,
+  // Uncached 3, Contiguous 4): tools/addr_probe.py compares them
+  if (!ptr || bytes <= 0) return VEON_ERR_BAD_ARG;
+  *ptr = nullptr;
+  if (hipExtMallocWithFlags(ptr, (size_t)bytes, flags) != hipSuccess) {
+    (void)hipGetLastError();
+    *ptr = nullptr;
+    return VEON_ERR_LAUNCH;
+  }
+  return VEON_OK;
+}
+
 int veon_free_device(void* ptr) {
   if (!ptr) return VEON_OK;
   return hipFree(ptr) == hipSuccess ? VEON_OK : VEON_ERR_LAUNCH;

@@ -31,7 +31,7 @@ class _ContiguousBlock:
     ``__cuda_array_interface__`` (the tensor made from it keeps this object, and
     so the memory, alive)."""
 
-    def __init__(self, shape, dtype, device):
+    def __init__(self, shape, dtype, device, flags=None):
         from . import _lib
         self._lib = _lib
         self.nbytes = torch.empty((), dtype=dtype).element_size()
@@ -39,7 +39,11 @@ class _ContiguousBlock:
             self.nbytes *= int(d)
         p = ctypes.c_void_p(0)
         with torch.cuda.device(device):
-            st = _lib.lib().veon_alloc_contiguous(ctypes.byref(p), self.nbytes)
+            if flags is None:
+                st = _lib.lib().veon_alloc_contiguous(ctypes.byref(p), self.nbytes)
+            else:
+                st = _lib.lib().veon_alloc_device_flags(ctypes.byref(p), self.nbytes,
+                                                        int(flags))
         if st != 0 or not p.value:
             raise MemoryError('no physically contiguous block of %d bytes' % self.nbytes)
         self.ptr, self.device = p.value, device
@@ -57,13 +61,14 @@ class _ContiguousBlock:
                 pass
 
 
-def contiguous_tensor(shape, dtype=torch.float32, device=None):
+def contiguous_tensor(shape, dtype=torch.float32, device=None, flags=None):
     """A tensor on physically contiguous VRAM (hipDeviceMallocContiguous), or None
-    when the driver cannot provide one."""
+    when the driver cannot provide one.  ``flags``: another hipExtMallocWithFlags
+    flag instead (1 fine-grained, 3 uncached; probe use)."""
     if _TYPESTR.get(dtype) is None:
         return None
     try:
-        block = _ContiguousBlock(shape, dtype, device)
+        block = _ContiguousBlock(shape, dtype, device, flags)
     except (MemoryError, AttributeError, OSError):
         return None
     return torch.as_tensor(block, device=device)
