@@ -156,6 +156,11 @@ int veon_bev_pool_v2_fwd_fused_ex(int c, int n_intervals, int batch,
                                   const int *interval_starts,
                                   const int *interval_lengths, const int *plan,
                                   float *out, int out_layout, void *stream);
+/* (images, C, HW) -> (images, HW, C), 4- or 2-byte elements: the
+ * `feat.permute(0, 1, 3, 4, 2)` of view_transform_core (view_transformer.py:273-275)
+ * made contiguous, as bev_pool_v2 does on entry (bev_pool.py:21). */
+int veon_feat_nchw_to_nhwc(const void *in, void *out, int elem_bytes, int images,
+                           int C, int HW, void *stream);
 /* As veon_bev_pool_v2_fwd_fused_ex with the (B,C,Z,Y,X) layout, but the channel
  * planes of `out` are `plane_stride` floats apart (>= voxels_per_batch): out is a
  * (B, C, plane_stride) buffer whose first voxels_per_batch floats of every plane

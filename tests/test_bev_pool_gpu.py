@@ -489,3 +489,25 @@ def test_fused_pool_into_padded_planes_equals_contiguous():
     assert torch.equal(got[:, :vpb], want)
     assert bool((got[:, vpb:] == -7.0).all())
     assert run(got, vpb - 1) != 0
+
+
+@pytest.mark.parametrize('dtype', ['float32', 'bfloat16', 'float16'])
+@pytest.mark.parametrize('B,N,C,H,W', [(1, 6, 80, 16, 44), (2, 3, 256, 5, 7), (1, 1, 17, 3, 65)])
+def test_feature_rows_transpose_kernel_equals_contiguous(dtype, B, N, C, H, W):
+    """bev_pool._rows: the permuted (B,N,C,H,W) -> (B,N,H,W,C) view made contiguous
+    by the LDS-tiled kernel is bit-identical to torch's .contiguous(); other
+    stride patterns take the torch path."""
+    import torch
+    from veon_amd import _lib
+    from veon_amd.ops.bev_pool_v2 import bev_pool as bp
+    dt = getattr(torch, dtype)
+    x = torch.randn(B, N, C, H, W, device='cuda:0').to(dt)
+    view = x.permute(0, 1, 3, 4, 2)
+    before = _lib.CALLS.get('veon_feat_nchw_to_nhwc', 0)
+    got = bp._rows(view)
+    assert _lib.CALLS.get('veon_feat_nchw_to_nhwc', 0) == before + 1
+    assert got.is_contiguous() and torch.equal(got, view.contiguous())
+    other = x.permute(0, 1, 4, 3, 2)            # not the lift's pattern
+    assert torch.equal(bp._rows(other), other.contiguous())
+    assert _lib.CALLS.get('veon_feat_nchw_to_nhwc', 0) == before + 1
+    assert bp._rows(got) is got

@@ -42,6 +42,7 @@ _SIGNATURES = {
     'veon_bev_pool_v2_fwd': (_ci, [_ci, _ci] + [_vp] * 8 + [_vp]),
     'veon_bev_pool_v2_bwd': (_ci, [_ci, _ci] + [_vp] * 10 + [_vp]),
     'veon_bev_pool_v2_fwd_fused': (_ci, [_ci, _ci, _ci, _i64] + [_vp] * 9 + [_ci, _vp]),
+    'veon_feat_nchw_to_nhwc': (_ci, [_vp, _vp] + [_ci] * 4 + [_vp]),
     'veon_bev_pool_v2_fwd_fused_strided': (_ci, [_ci, _ci, _ci, _i64, _vp, _vp, _ci] + [_vp] * 7 + [_i64, _vp]),
     'veon_bev_pool_v2_fwd_fused_ex': (_ci, [_ci, _ci, _ci, _i64, _vp, _vp, _ci] + [_vp] * 7 + [_ci, _vp]),
     'veon_bev_pool_v2_fwd_maxpool_ex': (_ci, [_ci] * 9 + [_vp, _vp, _ci] + [_vp] * 7 + [_vp]),

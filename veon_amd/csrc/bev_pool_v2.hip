@@ -663,6 +663,33 @@ inline bool aligned16(const void* p) {
 
 }  // namespace
 
+// (B*N, C, H*W) -> (B*N, H*W, C): the `feat.permute(0,1,3,4,2).contiguous()` in
+// front of the reference op (view_transformer.py:273-275 + bev_pool.py:21) as one
+// LDS-tiled transpose (64 pixels x 64 channels per workgroup; coalesced 256-byte
+// rows on both sides).  PyTorch's strided copy of this 1.35 MB tensor takes 5.5 us,
+// a sixth of the pool kernel it feeds.
+namespace {
+template <typename T>
+__global__ __launch_bounds__(256) void k_feat_nchw_to_nhwc(const T* __restrict__ in,
+                                                           T* __restrict__ out, int C,
+                                                           int HW) {
+  __shared__ T t[64][65];
+  const int p0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const T* ib = in + (int64_t)blockIdx.z * C * HW;
+  T* ob = out + (int64_t)blockIdx.z * HW * C;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int r = ty; r < 64; r += 4) {
+    const int c = c0 + r, p = p0 + tx;
+    if (c < C && p < HW) t[r][tx] = ib[(int64_t)c * HW + p];
+  }
+  __syncthreads();
+  for (int r = ty; r < 64; r += 4) {
+    const int p = p0 + r, c = c0 + tx;
+    if (p < HW && c < C) ob[(int64_t)p * C + c] = t[tx][r];
+  }
+}
+}  // namespace
+
 extern "C" {
 
 int veon_abi_version(void) { return VEON_ABI_VERSION; }
@@ -1027,6 +1054,23 @@ int veon_bev_pool_v2_fwd_fused(int c, int n_intervals, int batch,
       c, n_intervals, batch, voxels_per_batch, depth, feat, VEON_FEAT_F32,
       ranks_depth, ranks_feat, ranks_bev, interval_starts, interval_lengths,
       plan, out, out_layout, stream);
+}
+
+int veon_feat_nchw_to_nhwc(const void* in, void* out, int elem_bytes, int images,
+                           int C, int HW, void* stream) {
+  if (!in || !out || in == out || images <= 0 || C <= 0 || HW <= 0 ||
+      (elem_bytes != 4 && elem_bytes != 2) || images > 65535)
+    return VEON_ERR_BAD_ARG;
+  const dim3 grid((unsigned)((HW + 63) / 64), (unsigned)((C + 63) / 64), (unsigned)images);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (elem_bytes == 4)
+    hipLaunchKernelGGL(k_feat_nchw_to_nhwc<float>, grid, dim3(256), 0, s,
+                       static_cast<const float*>(in), static_cast<float*>(out), C, HW);
+  else
+    hipLaunchKernelGGL(k_feat_nchw_to_nhwc<unsigned short>, grid, dim3(256), 0, s,
+                       static_cast<const unsigned short*>(in),
+                       static_cast<unsigned short*>(out), C, HW);
+  return launch_status();
 }
 
 }  // extern "C"
