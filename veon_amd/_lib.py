@@ -153,4 +153,28 @@ def ptr(t):
 
 
 def stream_ptr(device):
-    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    """PyTorch's current stream on ``device`` as a raw hipStream_t (no Stream
+    object is built: this sits on every launch)."""
+    idx = device.index
+    if idx is None:
+        idx = torch.cuda.current_device()
+    return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(idx))
+
+
+class _NoGuard:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_GUARD = _NoGuard()
+
+
+def on_device(device):
+    """``torch.cuda.device(device)`` unless it is the current device already
+    (then a no-op context: the guard costs more than a small launch)."""
+    if device.index is None or device.index == torch.cuda.current_device():
+        return _NO_GUARD
+    return torch.cuda.device(device)

@@ -130,8 +130,12 @@ class LSSCore(_Base):
                             int(self.grid_size[0]))
 
     def _bev_feat_shape(self, B, C):
-        return (B, int(self.grid_size[2]), int(self.grid_size[1]),
-                int(self.grid_size[0]), C)  # (B, Z, Y, X, C)
+        zyx = self.__dict__.get('_grid_zyx')
+        if zyx is None or zyx[0] is not self.grid_size:   # grid_size tensor -> ints, once
+            gs = self.grid_size
+            zyx = (gs, int(gs[2]), int(gs[1]), int(gs[0]))
+            self.__dict__['_grid_zyx'] = zyx
+        return (B, zyx[1], zyx[2], zyx[3], C)  # (B, Z, Y, X, C)
 
     def voxel_pooling_v2(self, coor, depth, feat):
         """view_transformer_raw.py:217-242."""

@@ -77,7 +77,7 @@ def _rows(feat):
         B, N, H, W, C = feat.shape
         if feat.stride() == (N * C * H * W, C * H * W, W, 1, H * W) and B * N <= 65535:
             out = torch.empty((B, N, H, W, C), dtype=feat.dtype, device=feat.device)
-            with torch.cuda.device(feat.device):
+            with _lib.on_device(feat.device):
                 st = _lib.lib().veon_feat_nchw_to_nhwc(
                     _lib.ptr(feat), _lib.ptr(out), feat.element_size(), B * N, C, H * W,
                     _lib.stream_ptr(feat.device))
@@ -101,13 +101,15 @@ def _prep_inputs(depth, feat, ranks_depth, ranks_feat, ranks_bev,
     # casts of bev_pool.py:19-25 (no-ops for what the prepare produces)
     tag = getattr(interval_starts, '_veon_sorted', None)
     plan = getattr(interval_starts, '_veon_plan', None)
-    depth = depth.contiguous().float()
+    def as_(t, dtype):   # the casts are no-ops for what the prepare produces
+        return t if (t.dtype == dtype and t.is_contiguous()) else t.contiguous().to(dtype)
+    depth = as_(depth, torch.float32)
     feat = _inference_feat(feat, depth)
-    ranks_bev = ranks_bev.contiguous().int()
-    ranks_depth = ranks_depth.contiguous().int()
-    ranks_feat = ranks_feat.contiguous().int()
-    interval_lengths = interval_lengths.contiguous().int()
-    interval_starts = interval_starts.contiguous().int()
+    ranks_bev = as_(ranks_bev, torch.int32)
+    ranks_depth = as_(ranks_depth, torch.int32)
+    ranks_feat = as_(ranks_feat, torch.int32)
+    interval_lengths = as_(interval_lengths, torch.int32)
+    interval_starts = as_(interval_starts, torch.int32)
     if tag is not None:
         interval_starts._veon_sorted = tag
     if plan is not None:
@@ -159,7 +161,7 @@ def _fused_forward(depth, feat, ranks_depth, ranks_feat, ranks_bev,
     else:
         plan = build_plan(ranks_bev, interval_starts, B, Z * Y * X,
                           attach=False)
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         st = _lib.lib().veon_bev_pool_v2_fwd_fused_ex(
             C, interval_starts.numel(), B, Z * Y * X, _lib.ptr(depth),
             _lib.ptr(feat), _feat_code(feat), _lib.ptr(ranks_depth),
@@ -300,7 +302,7 @@ def bev_pool_v2_prepared(depth, feat, pre, bev_feat_shape, out=None):
     elif (tuple(out.shape) != (B, C, Z, Y, X) or out.dtype != torch.float32
           or not out.is_contiguous() or out.device != dev):
         raise _lib.VeonHipError('out must be a contiguous fp32 (B,C,Z,Y,X) tensor')
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         st = _lib.lib().veon_bev_pool_v2_fwd_fused_ex(
             C, pre.interval_starts.numel(), B, Z * Y * X, _lib.ptr(depth),
             _lib.ptr(feat), _feat_code(feat), _lib.ptr(pre.ranks_depth),
