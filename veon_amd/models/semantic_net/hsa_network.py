@@ -44,26 +44,53 @@ class FeedForward(NativeCacheMixin, nn.Module):
                                  nn.Linear(hidden_dim, out_dim))
         self.conv_dtype = None   # set with the ConvBlocks (set_conv_dtype)
 
-    def forward(self, x):
-        ln, fc1, _, fc2 = self.net
-        if (self.conv_dtype == torch.bfloat16 and x.is_cuda and not self.training
+    def _hip_ok(self, x):
+        _, fc1, _, fc2 = self.net
+        return (self.conv_dtype == torch.bfloat16 and x.is_cuda and not self.training
                 and not torch.is_grad_enabled() and fc1.in_features % 64 == 0
                 and fc1.out_features % 64 == 0 and fc2.out_features % 4 == 0
-                and x.dtype == torch.float32):
-            # LN -> GEMM(+bias, GELU) -> GEMM(+bias) on the MFMA kernels
-            if '_hip' not in self.__dict__:
-                self.__dict__['_hip'] = (
-                    vit_ops.to_bf16(fc1.weight.detach().float()),
-                    fc1.bias.detach().float().contiguous(),
-                    vit_ops.to_bf16(fc2.weight.detach().float()),
-                    fc2.bias.detach().float().contiguous())
-            w1, b1, w2, b2 = self.__dict__['_hip']
-            shp = x.shape
-            h = vit_ops.layernorm(x.contiguous().view(-1, shp[-1]), ln.weight.detach(),
-                                  ln.bias.detach(), ln.eps)
-            h = vit_ops.linear(h, w1, b1, vit_ops.EPI_GELU)
-            return vit_ops.linear(h, w2, b2).float().view(*shp[:-1], -1)
+                and x.dtype == torch.float32)
+
+    def _hip_hidden(self, x):
+        """LN -> GEMM(+bias, GELU) on the MFMA kernels -> bf16 (tokens, hidden)."""
+        ln, fc1, _, fc2 = self.net
+        if '_hip' not in self.__dict__:
+            self.__dict__['_hip'] = (
+                vit_ops.to_bf16(fc1.weight.detach().float()),
+                fc1.bias.detach().float().contiguous(),
+                vit_ops.to_bf16(fc2.weight.detach().float()),
+                fc2.bias.detach().float().contiguous())
+        w1, b1, w2, b2 = self.__dict__['_hip']
+        h = vit_ops.layernorm(x.contiguous().view(-1, x.shape[-1]), ln.weight.detach(),
+                              ln.bias.detach(), ln.eps)
+        return vit_ops.linear(h, w1, b1, vit_ops.EPI_GELU), w2, b2
+
+    def forward(self, x):
+        if self._hip_ok(x):
+            h, w2, b2 = self._hip_hidden(x)
+            return vit_ops.linear(h, w2, b2).float().view(*x.shape[:-1], -1)
         return self.net(x)
+
+    def forward_resized(self, x, side_shape, new_shape):
+        """``interpolate(self(x) as a (B, out, H, W) map, size=new_shape,
+        bilinear)`` -> contiguous (B, out, h, w).  The last Linear and the bilinear
+        resize are both linear and act on different axes, so on the MFMA path the
+        resize is applied to the hidden activations and the wide output GEMM runs
+        on the h*w tokens that survive it (16x fewer at VEON's shapes; the
+        (B, H*W, out) tensor -- 623 MB there -- is never formed).  Bilinear weights
+        sum to one, so the bias commutes too."""
+        B = x.shape[0]
+        H, W = side_shape
+        h, w = new_shape
+        if not self._hip_ok(x):
+            y = self(x).permute(0, 2, 1).reshape(B, -1, H, W)
+            return _interp(y, size=(h, w), mode='bilinear').contiguous()
+        hid, w2, b2 = self._hip_hidden(x)                       # (B*H*W, hidden) bf16
+        hid = hid.view(B, H, W, -1).permute(0, 3, 1, 2)          # NCHW view of NHWC rows
+        hid = F.interpolate(hid, size=(h, w), mode='bilinear')   # stays channels-last
+        rows = hid.permute(0, 2, 3, 1).reshape(B * h * w, -1)
+        y = vit_ops.linear(rows, w2, b2)                         # (B*h*w, out) bf16
+        return y.view(B, h * w, -1).permute(0, 2, 1).float().contiguous().view(B, -1, h, w)
 
 
 class ConvBlock(NativeCacheMixin, nn.Module):
@@ -187,18 +214,22 @@ class AttnManipulateBlock(nn.Module):
     def forward(self, x, side_shape=(1, 1), new_shape=(1, 1)):
         x = self.pre_norm(x)
         x = self.ln_4(self.ff(self.ln_3(x), side_shape))
-        attns = self.head_attn(x)
         supp = self.head_supp(x)
         H, W = side_shape
         h, w = new_shape
         B = x.shape[0]
-        attns = attns.permute(0, 2, 1).reshape(B, -1, H, W)
-        # (the reference reshapes the NCHW result to (B, h, w, -1) without a
-        # permute -- kept as is, :177-178)
-        attns = _interp(attns, size=(h, w), mode='bilinear').contiguous() \
-            .reshape(B, h, w, -1)
+        # head -> (B, C, H, W) map -> bilinear resize to CLIP's token grid; the
+        # reference then reshapes the NCHW result to (B, h, w, -1) without a
+        # permute -- kept as is (:177-178)
+        attns = self.head_attn.forward_resized(x, (H, W), (h, w)).reshape(B, h, w, -1)
         attns = attns.reshape(B, h * w, self.attn_layers, self.heads, self.dim_head)
-        attns = torch.einsum('bmahd,bnahd->bmnah', attns, attns).permute(3, 0, 4, 1, 2)
+        # Gram matrices per (layer, sample, head): the reference's
+        # einsum('bmahd,bnahd->bmnah').permute(3, 0, 4, 1, 2), i.e. (a, b, h, m, n),
+        # formed as one batched matmul that writes that layout contiguously (the
+        # einsum writes it with the layer / head axes innermost -- 36 floats apart
+        # -- and every consumer then copies it)
+        q = attns.permute(2, 0, 3, 1, 4)                       # (a, b, h, m, d)
+        attns = torch.matmul(q, q.transpose(-1, -2))
         supp = supp.permute(0, 2, 1).reshape(B, -1, H, W)
         return None, attns, supp
 
