@@ -403,6 +403,11 @@ int veon_alloc_contiguous(void **ptr, int64_t bytes);
 /* the same with any hipExtMallocWithFlags flag (probe tool) */
 int veon_alloc_device_flags(void **ptr, int64_t bytes, unsigned flags);
 int veon_free_device(void *ptr);
+/* nn.LayerNorm over the last dim, fp32 in -> fp32 out, rows of d floats
+ * (d % 128 == 0, d <= 1024): the token LayerNorms (ln_3 / ln_4 / pre_norm) of the
+ * HSA network's blocks (highres_side_adaptor.py:108-135, 138-193). */
+int veon_layernorm_f32(const float *x, const float *gamma, const float *beta,
+                       float *out, int T, int d, float eps, void *stream);
 /* LayerNorm over the channels of every pixel of a padded channels-last bf16 image:
  * the nn.LayerNorm calls of ConvBlock.forward (highres_side_adaptor.py:31-52) with
  * their permute / reshape pairs.  out_tokens_f32 = 0: out is a padded bf16 image of

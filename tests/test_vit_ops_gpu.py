@@ -153,3 +153,16 @@ def test_whole_block_call_equals_the_seven_ops(act, with_gamma, with_bias):
     # too-small workspace is refused, not overrun
     with pytest.raises(Exception):
         vit_ops.block_forward_(x0.clone(), w, B, T, ws[:ws.numel() // 2], bias)
+
+
+@pytest.mark.parametrize('T,d', [(1000, 384), (7, 128), (67584, 384), (33, 1024)])
+def test_layernorm_f32_matches_torch(T, d):
+    """veon_layernorm_f32 (fp32 in / out, half a wave per row) vs F.layer_norm."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(d + T)
+    x = (torch.randn(T, d, generator=g) * 3 + 1).to('cuda:0')
+    w = (torch.rand(d, generator=g) + 0.5).to('cuda:0')
+    b = torch.randn(d, generator=g).to('cuda:0')
+    got = vit_ops.layernorm_f32(x, w, b, 1e-5)
+    want = F.layer_norm(x, (d,), w, b, 1e-5)
+    torch.testing.assert_close(got, want, rtol=2e-5, atol=2e-5)

@@ -531,6 +531,77 @@ __global__ __launch_bounds__(256) void k_cast_bf16(const float* __restrict__ in,
 
 }  // namespace
 
+// fp32 -> fp32 LayerNorm over rows of d = 128*K floats, half a wave per row (three
+// float4 per lane at d = 384: the token LayerNorms of the HSA network, which run on
+// 100 MB tensors at VEON's resolution).  Two-pass statistics in registers.
+namespace {
+template <int K>
+__global__ __launch_bounds__(256) void k_layernorm_f32(
+    const float* __restrict__ x, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float* __restrict__ out, int T, float eps) {
+  constexpr int D = 128 * K;
+  const int l = threadIdx.x & 31;
+  const int64_t row = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);
+  if (row >= T) return;  // a whole half-wave leaves; the shuffles below stay inside one
+  const float4* p = reinterpret_cast<const float4*>(x + row * D);
+  float4 v[K];
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    v[k] = p[l + 32 * k];
+    s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+  }
+#pragma unroll
+  for (int d = 16; d >= 1; d >>= 1) s += __shfl_xor(s, d);
+  const float mean = s / D;
+  float sq = 0.f;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const float a = v[k].x - mean, b = v[k].y - mean, c = v[k].z - mean, e = v[k].w - mean;
+    sq += (a * a + b * b) + (c * c + e * e);
+  }
+#pragma unroll
+  for (int d = 16; d >= 1; d >>= 1) sq += __shfl_xor(sq, d);
+  const float rstd = rsqrtf(sq / D + eps);
+  const float4* g4 = reinterpret_cast<const float4*>(gamma);
+  const float4* b4 = reinterpret_cast<const float4*>(beta);
+  float4* o = reinterpret_cast<float4*>(out + row * D);
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const float4 g = g4[l + 32 * k], b = b4[l + 32 * k];
+    float4 r;
+    r.x = (v[k].x - mean) * rstd * g.x + b.x;
+    r.y = (v[k].y - mean) * rstd * g.y + b.y;
+    r.z = (v[k].z - mean) * rstd * g.z + b.z;
+    r.w = (v[k].w - mean) * rstd * g.w + b.w;
+    o[l + 32 * k] = r;
+  }
+}
+}  // namespace
+
+extern "C" int veon_layernorm_f32(const float* x, const float* gamma, const float* beta,
+                                  float* out, int T, int d, float eps, void* stream) {
+  if (!x || !gamma || !beta || !out || T <= 0 || d <= 0 || d % 128 != 0 || d > 1024)
+    return VEON_ERR_BAD_ARG;
+  if (!al16(x) || !al16(gamma) || !al16(beta) || !al16(out)) return VEON_ERR_BAD_ARG;
+  const dim3 grid((unsigned)((T + 7) / 8));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+#define VEON_LN32(K)                                                            \
+  hipLaunchKernelGGL(k_layernorm_f32<K>, grid, dim3(256), 0, s, x, gamma, beta, out, T, eps)
+  switch (d / 128) {
+    case 1: VEON_LN32(1); break;
+    case 2: VEON_LN32(2); break;
+    case 3: VEON_LN32(3); break;
+    case 4: VEON_LN32(4); break;
+    case 5: VEON_LN32(5); break;
+    case 6: VEON_LN32(6); break;
+    case 7: VEON_LN32(7); break;
+    default: VEON_LN32(8); break;
+  }
+#undef VEON_LN32
+  return launch_status();
+}
+
 extern "C" {
 
 int veon_vit_cast_bf16(const float* in, void* out, int64_t n, void* stream) {

@@ -34,6 +34,18 @@ def _interp(x, **kw):
     return F.interpolate(x, **kw)
 
 
+def _ln(mod, x, native):
+    """``mod(x)`` for the token LayerNorms of the blocks; with ``native`` (the
+    block runs its ConvBlock on the MFMA path) on the fp32 LayerNorm kernel."""
+    if (native and isinstance(mod, nn.LayerNorm) and x.is_cuda
+            and not torch.is_grad_enabled() and x.dtype == torch.float32
+            and x.shape[-1] % 128 == 0 and x.shape[-1] <= 1024
+            and mod.weight is not None and mod.bias is not None):
+        return vit_ops.layernorm_f32(x.contiguous(), mod.weight.detach(),
+                                     mod.bias.detach(), mod.eps)
+    return mod(x)
+
+
 class FeedForward(NativeCacheMixin, nn.Module):
     _native_cache = ('_hip',)
 
@@ -179,15 +191,16 @@ class HighresSideAdaptorBlock(nn.Module):
 
     def forward(self, x, x_pos, ext, ext_pos, offset=None, offset_shape=(1, 1)):
         B, C_clip, h_ext, w_ext = ext.shape
-        x = self.pre_norm(x)
-        x = self.ff(self.ln_3(x), offset_shape) + x
+        native = self.ff.conv_dtype == torch.bfloat16 and not self.training
+        x = _ln(self.pre_norm, x, native)
+        x = self.ff(_ln(self.ln_3, x, native), offset_shape) + x
         if offset is not None:
             offset = self.neck_add(offset.reshape(B, C_clip, -1).permute(0, 2, 1))
             offset = _interp(offset.permute(0, 2, 1).reshape(B, -1, h_ext, w_ext),
                              size=offset_shape)
             offset = offset.reshape(B, offset.shape[1], -1).permute(0, 2, 1)
             x = torch.cat([x[:, :-offset.shape[1]], x[:, -offset.shape[1]:] + offset], 1)
-        return self.ln_4(x)
+        return _ln(self.ln_4, x, native)
 
 
 class AttnManipulateBlock(nn.Module):
@@ -212,8 +225,9 @@ class AttnManipulateBlock(nn.Module):
         self.ln_4 = nn.LayerNorm(mlp_dim)
 
     def forward(self, x, side_shape=(1, 1), new_shape=(1, 1)):
-        x = self.pre_norm(x)
-        x = self.ln_4(self.ff(self.ln_3(x), side_shape))
+        native = self.ff.conv_dtype == torch.bfloat16 and not self.training
+        x = _ln(self.pre_norm, x, native)
+        x = _ln(self.ln_4, self.ff(_ln(self.ln_3, x, native), side_shape), native)
         supp = self.head_supp(x)
         H, W = side_shape
         h, w = new_shape

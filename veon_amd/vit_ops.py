@@ -46,6 +46,21 @@ def layernorm(x, weight, bias, eps=1e-6, out=None):
     return out
 
 
+def layernorm_f32(x, weight, bias, eps=1e-5):
+    """x fp32 [..., d] -> fp32 [..., d] (nn.LayerNorm over the last dim);
+    d % 128 == 0, d <= 1024."""
+    dev = _dev(x, weight, bias)
+    d = x.shape[-1]
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    out = torch.empty_like(x)
+    with _lib.on_device(dev):
+        st = _lib.lib().veon_layernorm_f32(
+            _lib.ptr(x), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(out), x.numel() // d, d,
+            float(eps), _lib.stream_ptr(dev))
+    _lib.check(st, 'veon_layernorm_f32')
+    return out
+
+
 def linear(a, w, bias=None, epilogue=EPI_BF16, out=None, gamma=None):
     """a bf16 [M,K], w bf16 [N,K] (nn.Linear layout) -> bf16 [M,N].  ``gamma``
     (fp32 [N]) is the per-feature scale of the EPI_AFFINE* epilogues."""
