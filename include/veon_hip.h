@@ -412,10 +412,13 @@ int veon_layernorm_f32(const float *x, const float *gamma, const float *beta,
  * the nn.LayerNorm calls of ConvBlock.forward (highres_side_adaptor.py:31-52) with
  * their permute / reshape pairs.  out_tokens_f32 = 0: out is a padded bf16 image of
  * the same shape, halo written as zeros (input of the next 3x3 conv); 1: out is the
- * compact fp32 token tensor (B, Y*X, C).  C % 8 == 0, C <= 1024. */
+ * compact fp32 token tensor (B, Y*X, C), plus resid_tokens (same shape, fp32, may
+ * be NULL): the `ConvBlock(ln_3(x)) + x` of the adaptor block (:122).
+ * C % 8 == 0, C <= 1024. */
 int veon_image_layernorm_bf16(const void *in_padded, const float *gamma,
                               const float *beta, void *out, int out_tokens_f32, int B,
-                              int C, int Y, int X, float eps, void *stream);
+                              int C, int Y, int X, float eps, const float *resid_tokens,
+                              void *stream);
 /* ---- temporal path, csrc/temporal.hip ---------------------
  * Sampling + attention core of TemporalDeformable.forward
  * (mmdet3d/models/semantic_net/side_adapter/align_net_occ3d.py:138-196), replacing

@@ -471,6 +471,9 @@ def test_image_layernorm_matches_torch(C, Y, X):
     want = F.layer_norm(x.permute(0, 2, 3, 1), (C,), gamma, beta, 1e-5)     # (B,Y,X,C)
     tok = conv3d_ops.image_layernorm(img, gamma, beta, 1e-5, tokens=True)
     torch.testing.assert_close(tok, want.reshape(B, Y * X, C), rtol=1e-5, atol=1e-5)
+    res = torch.randn(B, Y * X, C, generator=g).to(DEV)
+    tok2 = conv3d_ops.image_layernorm(img, gamma, beta, 1e-5, tokens=True, residual=res)
+    torch.testing.assert_close(tok2, want.reshape(B, Y * X, C) + res, rtol=1e-5, atol=1e-5)
     out = conv3d_ops.image_layernorm(img, gamma, beta, 1e-5)
     grid = out.rows.view(B, Y + 2, X + 2, C).float()
     _close(grid[:, 1:-1, 1:-1], want)

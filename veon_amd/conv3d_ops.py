@@ -262,9 +262,10 @@ def conv2d_k3(img, w_packed, scale=None, shift=None, resid=None, relu=False,
     return out
 
 
-def image_layernorm(img, gamma, beta, eps, out=None, tokens=False):
+def image_layernorm(img, gamma, beta, eps, out=None, tokens=False, residual=None):
     """LayerNorm over the channels of every pixel of a PaddedImage.  ``tokens``
-    False: -> PaddedImage (zero halo); True: -> fp32 tokens (B, Y*X, C)."""
+    False: -> PaddedImage (zero halo); True: -> fp32 tokens (B, Y*X, C), plus
+    ``residual`` (fp32 tokens of that shape) when given."""
     dev = _lib.require_device(img.storage, gamma, beta)
     B, C, Y, X = img.shape
     assert gamma.dtype == beta.dtype == torch.float32 and gamma.numel() == beta.numel() == C
@@ -272,16 +273,20 @@ def image_layernorm(img, gamma, beta, eps, out=None, tokens=False):
         if out is None:
             out = torch.empty((B, Y * X, C), dtype=torch.float32, device=dev)
         assert out.is_contiguous() and tuple(out.shape) == (B, Y * X, C)
+        if residual is not None:
+            assert (residual.dtype == torch.float32 and residual.is_contiguous()
+                    and tuple(residual.shape) == (B, Y * X, C))
         dst = out
     else:
         if out is None:
             out = PaddedImage(B, C, Y, X, dev)
-        assert out.shape == img.shape and out is not img
+        assert out.shape == img.shape and out is not img and residual is None
         dst = out.rows
     with torch.cuda.device(dev):
         st = _lib.lib().veon_image_layernorm_bf16(
             _lib.ptr(img.rows), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(dst),
-            1 if tokens else 0, B, C, Y, X, float(eps), _lib.stream_ptr(dev))
+            1 if tokens else 0, B, C, Y, X, float(eps), _lib.ptr(residual),
+            _lib.stream_ptr(dev))
     _lib.check(st, 'veon_image_layernorm_bf16')
     return out
 

@@ -359,7 +359,9 @@ template <bool TOKENS>
 __global__ __launch_bounds__(256) void k_image_layernorm(
     const bf16_t* __restrict__ in, const float* __restrict__ gamma,
     const float* __restrict__ beta, void* __restrict__ out, int B, int Y, int X, int C,
-    float eps) {
+    float eps, const float* __restrict__ resid) {
+  // resid (TOKENS only, may be null): fp32 tokens added to the result, the
+  // `ConvBlock(ln_3(x)) + x` of the adaptor block (highres_side_adaptor.py:122)
   const int lane = threadIdx.x & 63;
   const int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int Yp = Y + 2, Xp = X + 2;
@@ -412,8 +414,14 @@ __global__ __launch_bounds__(256) void k_image_layernorm(
     for (int k = 0; k < 8; ++k)
       r[k] = (v[8 * h + k] - mean) * rstd * gamma[c0 + k] + beta[c0 + k];
     if (TOKENS) {
-      float* o = static_cast<float*>(out) +
-                 (((int64_t)b * Y + (y - 1)) * X + (x - 1)) * C + c0;
+      const int64_t to = (((int64_t)b * Y + (y - 1)) * X + (x - 1)) * C + c0;
+      if (resid != nullptr) {
+        const float4 a = *reinterpret_cast<const float4*>(resid + to);
+        const float4 e = *reinterpret_cast<const float4*>(resid + to + 4);
+        r[0] += a.x; r[1] += a.y; r[2] += a.z; r[3] += a.w;
+        r[4] += e.x; r[5] += e.y; r[6] += e.z; r[7] += e.w;
+      }
+      float* o = static_cast<float*>(out) + to;
       *reinterpret_cast<float4*>(o) = float4{r[0], r[1], r[2], r[3]};
       *reinterpret_cast<float4*>(o + 4) = float4{r[4], r[5], r[6], r[7]};
     } else {
@@ -636,7 +644,9 @@ int veon_image_dot(const void* in_padded, const float* w, float bias, float* out
 
 int veon_image_layernorm_bf16(const void* in_padded, const float* gamma,
                               const float* beta, void* out, int out_tokens_f32, int B,
-                              int C, int Y, int X, float eps, void* stream) {
+                              int C, int Y, int X, float eps, const float* resid_tokens,
+                              void* stream) {
+  if (resid_tokens && (!out_tokens_f32 || !al16(resid_tokens))) return VEON_ERR_BAD_ARG;
   if (B <= 0 || Y <= 0 || X <= 0 || C <= 0 || C % 8 != 0 || C > 1024 || !in_padded ||
       !gamma || !beta || !out || in_padded == out)
     return VEON_ERR_BAD_ARG;
@@ -648,10 +658,10 @@ int veon_image_layernorm_bf16(const void* in_padded, const float* gamma,
   const bf16_t* I = static_cast<const bf16_t*>(in_padded);
   if (out_tokens_f32)
     hipLaunchKernelGGL(k_image_layernorm<true>, dim3((unsigned)blocks), dim3(256), 0, s, I,
-                       gamma, beta, out, B, Y, X, C, eps);
+                       gamma, beta, out, B, Y, X, C, eps, resid_tokens);
   else
     hipLaunchKernelGGL(k_image_layernorm<false>, dim3((unsigned)blocks), dim3(256), 0, s, I,
-                       gamma, beta, out, B, Y, X, C, eps);
+                       gamma, beta, out, B, Y, X, C, eps, nullptr);
   return launch_status();
 }
 

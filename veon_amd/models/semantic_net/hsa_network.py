@@ -128,7 +128,7 @@ class ConvBlock(NativeCacheMixin, nn.Module):
                 and self.dim % 64 == 0 and self.h_dim % 64 == 0
                 and self.h_dim % 8 == 0 and self.out_dim % 8 == 0)
 
-    def _hip_forward(self, x, size):
+    def _hip_forward(self, x, size, residual=None):
         B, L, _ = x.shape
         H, W = size
         st = self.__dict__.setdefault('_hip', {})
@@ -157,14 +157,22 @@ class ConvBlock(NativeCacheMixin, nn.Module):
         # the fp32 tokens
         conv3d_ops.image_layernorm(b, g1, e1, self.ln1.eps, out=c)
         conv3d_ops.conv2d_k3(c, w2, None, b2, out=d)
-        return conv3d_ops.image_layernorm(d, g2, e2, self.ln2.eps, tokens=True)
+        if residual is not None:
+            residual = residual.contiguous().view(B, L, self.out_dim)
+        return conv3d_ops.image_layernorm(d, g2, e2, self.ln2.eps, tokens=True,
+                                          residual=residual)
 
-    def forward(self, x, size=(1, 1)):
+    def forward(self, x, size=(1, 1), residual=None):
+        """``residual`` (tokens of the output shape): added to the result (in the
+        last kernel on the MFMA path)."""
         B, L, dim = x.shape
         H, W = size
         assert H * W == L
-        if self._hip_ok(x):
-            return self._hip_forward(x, size)
+        if self._hip_ok(x) and (residual is None or (
+                residual.dtype == torch.float32 and residual.shape[-1] == self.out_dim)):
+            return self._hip_forward(x, size, residual)
+        if residual is not None:
+            return self.forward(x, size) + residual
         x = x.permute(0, 2, 1).reshape(B, dim, H, W).contiguous()
         x = self.gelu(self.conv1(x))
         x = self.ln1(x.reshape(B, self.h_dim, L).permute(0, 2, 1))
@@ -193,7 +201,7 @@ class HighresSideAdaptorBlock(nn.Module):
         B, C_clip, h_ext, w_ext = ext.shape
         native = self.ff.conv_dtype == torch.bfloat16 and not self.training
         x = _ln(self.pre_norm, x, native)
-        x = self.ff(_ln(self.ln_3, x, native), offset_shape) + x
+        x = self.ff(_ln(self.ln_3, x, native), offset_shape, residual=x)
         if offset is not None:
             offset = self.neck_add(offset.reshape(B, C_clip, -1).permute(0, 2, 1))
             offset = _interp(offset.permute(0, 2, 1).reshape(B, -1, h_ext, w_ext),
