@@ -408,6 +408,12 @@ int veon_free_device(void *ptr);
  * HSA network's blocks (highres_side_adaptor.py:108-135, 138-193). */
 int veon_layernorm_f32(const float *x, const float *gamma, const float *beta,
                        float *out, int T, int d, float eps, void *stream);
+/* the same LayerNorm of (B, Y*X, d) fp32 tokens, written as bf16 into the interior
+ * of a zero-haloed channels-last image [B][Y+2][X+2][d] (halo untouched): ln_3
+ * followed by the ConvBlock's permute / reshape to a feature map (:113-122, :38-40). */
+int veon_layernorm_f32_to_padded(const float *x, const float *gamma, const float *beta,
+                                 void *out_padded, int B, int Y, int X, int d,
+                                 float eps, void *stream);
 /* LayerNorm over the channels of every pixel of a padded channels-last bf16 image:
  * the nn.LayerNorm calls of ConvBlock.forward (highres_side_adaptor.py:31-52) with
  * their permute / reshape pairs.  out_tokens_f32 = 0: out is a padded bf16 image of

@@ -480,3 +480,33 @@ def test_image_layernorm_matches_torch(C, Y, X):
     halo = grid.clone()
     halo[:, 1:-1, 1:-1] = 0
     assert float(halo.abs().sum()) == 0.0
+
+
+def test_layernorm_tokens_to_padded_image_and_convblock_fusions():
+    """veon_layernorm_f32_to_padded == LayerNorm + staging into the padded bf16
+    image; and a dim-384 ConvBlock with pre_ln / residual folded into its first /
+    last kernel agrees with the same block given them separately."""
+    from veon_amd.models.semantic_net.hsa_network import ConvBlock
+    g = torch.Generator().manual_seed(9)
+    B, Y, X, C = 2, 5, 7, 384
+    x = (torch.randn(B, Y * X, C, generator=g) * 2 + 0.3).to(DEV)
+    ln = torch.nn.LayerNorm(C).to(DEV)
+    with torch.no_grad():
+        ln.weight.uniform_(0.5, 1.5)
+        ln.bias.normal_(0, 0.3)
+        img = conv3d_ops.PaddedImage(B, C, Y, X, DEV)
+        conv3d_ops.layernorm_tokens_to_image(x, ln.weight, ln.bias, ln.eps, img)
+        want = ln(x).view(B, Y, X, C)
+        grid = img.rows.view(B, Y + 2, X + 2, C).float()
+        _close(grid[:, 1:-1, 1:-1], want)
+        halo = grid.clone()
+        halo[:, 1:-1, 1:-1] = 0
+        assert float(halo.abs().sum()) == 0.0
+        blk = ConvBlock(C, C).to(DEV).eval()
+        blk.conv_dtype = torch.bfloat16
+        before = _lib.CALLS.get('veon_layernorm_f32_to_padded', 0)
+        fused = blk(x, (Y, X), residual=x, pre_ln=ln)
+        assert _lib.CALLS.get('veon_layernorm_f32_to_padded', 0) == before + 1
+        apart = blk(ln(x), (Y, X)) + x
+    rel = ((fused - apart).norm() / apart.norm()).item()
+    assert rel < 5e-3, rel

@@ -291,6 +291,20 @@ def image_layernorm(img, gamma, beta, eps, out=None, tokens=False, residual=None
     return out
 
 
+def layernorm_tokens_to_image(x, gamma, beta, eps, out):
+    """nn.LayerNorm of fp32 tokens (B, Y*X, C) written as bf16 into the interior of
+    the PaddedImage ``out`` (its halo is left as it is: zero)."""
+    dev = _lib.require_device(x, gamma, beta, out.storage)
+    B, C, Y, X = out.shape
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.numel() == B * Y * X * C
+    with _lib.on_device(dev):
+        st = _lib.lib().veon_layernorm_f32_to_padded(
+            _lib.ptr(x), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(out.rows), B, Y, X, C,
+            float(eps), _lib.stream_ptr(dev))
+    _lib.check(st, 'veon_layernorm_f32_to_padded')
+    return out
+
+
 def resize_bilinear(img, size, out=None):
     """F.interpolate(mode='bilinear', align_corners=True) on a PaddedImage."""
     dev = _lib.require_device(img.storage)

@@ -535,10 +535,14 @@ __global__ __launch_bounds__(256) void k_cast_bf16(const float* __restrict__ in,
 // float4 per lane at d = 384: the token LayerNorms of the HSA network, which run on
 // 100 MB tensors at VEON's resolution).  Two-pass statistics in registers.
 namespace {
-template <int K>
+// PADDED: instead of fp32 rows, write bf16 into the interior of a zero-haloed
+// channels-last image [B][Y+2][X+2][D] (token t = (b, y, x)): LayerNorm + the
+// ConvBlock's input staging in one pass.
+template <int K, bool PADDED>
 __global__ __launch_bounds__(256) void k_layernorm_f32(
     const float* __restrict__ x, const float* __restrict__ gamma,
-    const float* __restrict__ beta, float* __restrict__ out, int T, float eps) {
+    const float* __restrict__ beta, void* __restrict__ out, int T, float eps, int Y,
+    int X) {
   constexpr int D = 128 * K;
   const int l = threadIdx.x & 31;
   const int64_t row = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);
@@ -565,7 +569,11 @@ __global__ __launch_bounds__(256) void k_layernorm_f32(
   const float rstd = rsqrtf(sq / D + eps);
   const float4* g4 = reinterpret_cast<const float4*>(gamma);
   const float4* b4 = reinterpret_cast<const float4*>(beta);
-  float4* o = reinterpret_cast<float4*>(out + row * D);
+  int64_t orow = row;
+  if (PADDED) {
+    const int64_t px = row % X, py = (row / X) % Y, pb = row / ((int64_t)X * Y);
+    orow = (pb * (Y + 2) + py + 1) * (X + 2) + px + 1;
+  }
 #pragma unroll
   for (int k = 0; k < K; ++k) {
     const float4 g = g4[l + 32 * k], b = b4[l + 32 * k];
@@ -574,20 +582,36 @@ __global__ __launch_bounds__(256) void k_layernorm_f32(
     r.y = (v[k].y - mean) * rstd * g.y + b.y;
     r.z = (v[k].z - mean) * rstd * g.z + b.z;
     r.w = (v[k].w - mean) * rstd * g.w + b.w;
-    o[l + 32 * k] = r;
+    if (PADDED) {
+      bf16x4 o4;
+      o4[0] = (short)f2bf(r.x); o4[1] = (short)f2bf(r.y);
+      o4[2] = (short)f2bf(r.z); o4[3] = (short)f2bf(r.w);
+      reinterpret_cast<bf16x4*>(static_cast<bf16_t*>(out) + orow * D)[l + 32 * k] = o4;
+    } else {
+      reinterpret_cast<float4*>(static_cast<float*>(out) + orow * D)[l + 32 * k] = r;
+    }
   }
 }
 }  // namespace
 
-extern "C" int veon_layernorm_f32(const float* x, const float* gamma, const float* beta,
-                                  float* out, int T, int d, float eps, void* stream) {
+static int layernorm_f32_impl(const float* x, const float* gamma, const float* beta,
+                              void* out, int T, int d, float eps, int Y, int X,
+                              bool padded, void* stream) {
   if (!x || !gamma || !beta || !out || T <= 0 || d <= 0 || d % 128 != 0 || d > 1024)
     return VEON_ERR_BAD_ARG;
   if (!al16(x) || !al16(gamma) || !al16(beta) || !al16(out)) return VEON_ERR_BAD_ARG;
+  if (padded && (Y <= 0 || X <= 0 || T % ((int64_t)Y * X) != 0)) return VEON_ERR_BAD_ARG;
   const dim3 grid((unsigned)((T + 7) / 8));
   hipStream_t s = static_cast<hipStream_t>(stream);
 #define VEON_LN32(K)                                                            \
-  hipLaunchKernelGGL(k_layernorm_f32<K>, grid, dim3(256), 0, s, x, gamma, beta, out, T, eps)
+  do {                                                                          \
+    if (padded)                                                                 \
+      hipLaunchKernelGGL((k_layernorm_f32<K, true>), grid, dim3(256), 0, s, x, gamma,  \
+                         beta, out, T, eps, Y, X);                              \
+    else                                                                        \
+      hipLaunchKernelGGL((k_layernorm_f32<K, false>), grid, dim3(256), 0, s, x, gamma, \
+                         beta, out, T, eps, 1, 1);                              \
+  } while (0)
   switch (d / 128) {
     case 1: VEON_LN32(1); break;
     case 2: VEON_LN32(2); break;
@@ -600,6 +624,21 @@ extern "C" int veon_layernorm_f32(const float* x, const float* gamma, const floa
   }
 #undef VEON_LN32
   return launch_status();
+}
+
+extern "C" int veon_layernorm_f32(const float* x, const float* gamma, const float* beta,
+                                  float* out, int T, int d, float eps, void* stream) {
+  return layernorm_f32_impl(x, gamma, beta, out, T, d, eps, 1, 1, false, stream);
+}
+
+extern "C" int veon_layernorm_f32_to_padded(const float* x, const float* gamma,
+                                            const float* beta, void* out_padded, int B,
+                                            int Y, int X, int d, float eps,
+                                            void* stream) {
+  if (B <= 0 || Y <= 0 || X <= 0 || (int64_t)B * Y * X > 0x7fffffffLL)
+    return VEON_ERR_BAD_ARG;
+  return layernorm_f32_impl(x, gamma, beta, out_padded, B * Y * X, d, eps, Y, X, true,
+                            stream);
 }
 
 extern "C" {

@@ -128,7 +128,7 @@ class ConvBlock(NativeCacheMixin, nn.Module):
                 and self.dim % 64 == 0 and self.h_dim % 64 == 0
                 and self.h_dim % 8 == 0 and self.out_dim % 8 == 0)
 
-    def _hip_forward(self, x, size, residual=None):
+    def _hip_forward(self, x, size, residual=None, pre_ln=None):
         B, L, _ = x.shape
         H, W = size
         st = self.__dict__.setdefault('_hip', {})
@@ -149,8 +149,16 @@ class ConvBlock(NativeCacheMixin, nn.Module):
 
         def interior(img):
             return img.rows.view(B, H + 2, W + 2, -1)[:, 1:-1, 1:-1]
-        # tokens are channels-last already: one strided copy into the interior
-        interior(a).copy_(x.view(B, H, W, self.dim))
+        if (pre_ln is not None and x.dtype == torch.float32 and self.dim % 128 == 0
+                and self.dim <= 1024):
+            # the block's LayerNorm and the staging of the conv input in one pass
+            conv3d_ops.layernorm_tokens_to_image(
+                x.contiguous(), pre_ln.weight.detach(), pre_ln.bias.detach(), pre_ln.eps, a)
+        else:
+            if pre_ln is not None:
+                x = pre_ln(x)
+            # tokens are channels-last already: one strided copy into the interior
+            interior(a).copy_(x.view(B, H, W, self.dim))
         conv3d_ops.conv2d_k3(a, w1, None, b1, act='gelu', out=b)
         # LayerNorm over the channels of every pixel on the padded rows (fp32
         # statistics): the first writes the next conv's padded input, the second
@@ -162,15 +170,18 @@ class ConvBlock(NativeCacheMixin, nn.Module):
         return conv3d_ops.image_layernorm(d, g2, e2, self.ln2.eps, tokens=True,
                                           residual=residual)
 
-    def forward(self, x, size=(1, 1), residual=None):
-        """``residual`` (tokens of the output shape): added to the result (in the
-        last kernel on the MFMA path)."""
+    def forward(self, x, size=(1, 1), residual=None, pre_ln=None):
+        """``pre_ln`` (an nn.LayerNorm): applied to ``x`` first; ``residual``
+        (tokens of the output shape): added to the result.  Both fold into the
+        first / last kernel on the MFMA path."""
         B, L, dim = x.shape
         H, W = size
         assert H * W == L
         if self._hip_ok(x) and (residual is None or (
                 residual.dtype == torch.float32 and residual.shape[-1] == self.out_dim)):
-            return self._hip_forward(x, size, residual)
+            return self._hip_forward(x, size, residual, pre_ln)
+        if pre_ln is not None:
+            x = pre_ln(x)
         if residual is not None:
             return self.forward(x, size) + residual
         x = x.permute(0, 2, 1).reshape(B, dim, H, W).contiguous()
@@ -201,7 +212,7 @@ class HighresSideAdaptorBlock(nn.Module):
         B, C_clip, h_ext, w_ext = ext.shape
         native = self.ff.conv_dtype == torch.bfloat16 and not self.training
         x = _ln(self.pre_norm, x, native)
-        x = self.ff(_ln(self.ln_3, x, native), offset_shape, residual=x)
+        x = self.ff(x, offset_shape, residual=x, pre_ln=self.ln_3)
         if offset is not None:
             offset = self.neck_add(offset.reshape(B, C_clip, -1).permute(0, 2, 1))
             offset = _interp(offset.permute(0, 2, 1).reshape(B, -1, h_ext, w_ext),
@@ -235,7 +246,7 @@ class AttnManipulateBlock(nn.Module):
     def forward(self, x, side_shape=(1, 1), new_shape=(1, 1)):
         native = self.ff.conv_dtype == torch.bfloat16 and not self.training
         x = _ln(self.pre_norm, x, native)
-        x = _ln(self.ln_4, self.ff(_ln(self.ln_3, x, native), side_shape), native)
+        x = _ln(self.ln_4, self.ff(x, side_shape, pre_ln=self.ln_3), native)
         supp = self.head_supp(x)
         H, W = side_shape
         h, w = new_shape
