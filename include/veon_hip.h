@@ -141,6 +141,51 @@ int veon_bev_pool_v2_fwd_maxpool(int c, int n_intervals, int batch, int Z, int Y
                                  void *stream);
 
 /*
+ * ---- "row" kernels: the wide-channel shapes (VEON: C = 256) ----------------
+ * Same arithmetic as the fused entry points above (serial fmaf chain per voxel
+ * in storage order, bev_pool_cuda.cu:38-43), different decomposition: the index
+ * side is ONE dense table
+ *     vstart[B*voxels_per_batch + 1]:  voxel v owns points
+ *     [vstart[v], vstart[v+1]) of the rank-sorted arrays
+ * (the exclusive scan of the voxel histogram -- veon_lss_prepare emits it as
+ * `vstart`; veon_bev_pool_voxel_table builds it from the reference's arrays
+ * ranks_bev / interval_starts, which must be ascending in voxel rank and tile
+ * the point arrays, i.e. starts[i+1] == starts[i] + lengths[i] -- what
+ * voxel_pooling_prepare_v2 produces, view_transformer_raw.py:287-299); the
+ * gather side reads every feature row once per workgroup as one full-width wave
+ * load (lanes = channels).  ranks_bev / interval_* are not read by the kernels.
+ *
+ * veon_bev_pool_v2_fwd_rows: zero-fill + pool + (B,C,Z,Y,X) layout in one pass
+ *   (as veon_bev_pool_v2_fwd_fused_strided; plane_stride 0 = contiguous).
+ *   c even.  `variant` selects the tile shape (0 = default).
+ * veon_bev_pool_v2_fwd_rows_maxpool: pool + (2,2,2) block max
+ *   (LSSViewTransformerRaw.forward, view_transformer_raw.py:545-553).
+ *   out_padded_bf16 = 0: out is (B,C,Z/2,Y/2,X/2) fp32;  1: out is the interior
+ *   of the Conv3d body's zero-padded channels-last bf16 grid (as
+ *   veon_bev_pool_v2_fwd_maxpool_padded).  c % 4 == 0.
+ * depth_sorted_ws (optional, one float per kept point, i.e. vstart's last entry;
+ *   the capacity of ranks_depth is always enough): when given, a pre-pass writes
+ *   depth[ranks_depth[q]] there and the kernels read it linearly -- one dependent
+ *   load level less in every wave (same values, so bit-identical results).
+ */
+int64_t veon_bev_pool_voxel_table_ints(int batch, int64_t voxels_per_batch);
+int veon_bev_pool_voxel_table(int n_intervals, int n_points, int batch,
+                              int64_t voxels_per_batch, const int *ranks_bev,
+                              const int *interval_starts, const int *counts,
+                              int *vstart, void *stream);
+int veon_bev_pool_v2_fwd_rows(int c, int batch, int64_t voxels_per_batch,
+                              const float *depth, const void *feat, int feat_dtype,
+                              const int *ranks_depth, const int *ranks_feat,
+                              const int *vstart, float *depth_sorted_ws, float *out,
+                              int64_t plane_stride, int variant, void *stream);
+int veon_bev_pool_v2_fwd_rows_maxpool(int c, int batch, int Z, int Y, int X, int dz,
+                                      int dy, int dx, const float *depth,
+                                      const void *feat, int feat_dtype,
+                                      const int *ranks_depth, const int *ranks_feat,
+                                      const int *vstart, float *depth_sorted_ws,
+                                      void *out, int out_padded_bf16, void *stream);
+
+/*
  * Half-precision feature rows.  QuickCumsumCuda.forward widens feat to fp32
  * before the kernel (bev_pool.py:21 `feat.contiguous().float()`); the *_ex
  * entry points read fp16 / bf16 rows (`feat_dtype` = VEON_FEAT_*) and widen in

@@ -209,7 +209,7 @@ def test_prepare_plan_equals_standalone_plan(name):
     g = load_golden(name)
     vt = _raw_from_golden(g)
     rb, rd, rf, st, ln = vt.voxel_pooling_prepare_v2(dev(g['coor']))
-    plan, B, vpb = st._veon_plan
+    plan, (B, vpb), _ = st._veon_plan
     n_tiles = B * (vpb // 64)
     ref = bp.build_plan(rb, st, B, vpb, attach=False)
     assert torch.equal(plan[:4 * n_tiles], ref[:4 * n_tiles])

@@ -48,6 +48,12 @@ _SIGNATURES = {
     'veon_bev_pool_v2_fwd_maxpool_ex': (_ci, [_ci] * 9 + [_vp, _vp, _ci] + [_vp] * 7 + [_vp]),
     'veon_bev_pool_v2_fwd_maxpool_padded': (_ci, [_ci] * 9 + [_vp, _vp, _ci] + [_vp] * 7 + [_vp]),
     'veon_bev_pool_tile_voxels': (_ci, []),
+    'veon_bev_pool_voxel_table_ints': (_i64, [_ci, _i64]),
+    'veon_bev_pool_voxel_table': (_ci, [_ci, _ci, _ci, _i64, _vp, _vp, _vp, _vp, _vp]),
+    'veon_bev_pool_v2_fwd_rows': (_ci, [_ci, _ci, _i64, _vp, _vp, _ci, _vp, _vp, _vp, _vp, _vp,
+                                        _i64, _ci, _vp]),
+    'veon_bev_pool_v2_fwd_rows_maxpool': (_ci, [_ci] * 8 + [_vp, _vp, _ci, _vp, _vp, _vp, _vp,
+                                                _vp, _ci, _vp]),
     'veon_bev_pool_plan_ints': (_i64, [_ci, _i64]),
     'veon_bev_pool_plan': (_ci, [_ci, _ci, _ci, _i64, _vp, _vp, _vp, _vp, _vp]),
     'veon_bev_pool_row_table': (_ci, [_ci, _ci, _ci, _i64, _ci, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -47,10 +47,44 @@ def hipcc():
     return 'hipcc'
 
 
-def build(force=False, verbose=False):
+def _obj(src):
+    return os.path.join(HERE, '_build', os.path.basename(src)[:-4] + '.o')
+
+
+def _stale(obj, src):
+    if not os.path.exists(obj):
+        return True
+    t = os.path.getmtime(obj)
+    headers = glob.glob(os.path.join(CSRC, '*.h')) + glob.glob(os.path.join(INCLUDE, '*.h'))
+    return any(os.path.getmtime(d) > t for d in [src] + headers)
+
+
+def build(force=False, verbose=False, jobs=None):
+    """One object per .hip (compiled in parallel, only the stale ones), then one
+    link: an edit of one kernel file rebuilds in seconds."""
     if not force and up_to_date():
         return LIB
-    cmd = [hipcc()] + FLAGS + ['-I', INCLUDE, '-o', LIB] + sources()
+    os.makedirs(os.path.join(HERE, '_build'), exist_ok=True)
+    cflags = [f for f in FLAGS if f != '-shared']
+    todo = [s for s in sources() if force or _stale(_obj(s), s)]
+    jobs = jobs or min(len(todo), max(1, (os.cpu_count() or 2) // 2)) or 1
+    procs, failed = [], False
+    pending = list(todo)
+    while pending or procs:
+        while pending and len(procs) < jobs:
+            src = pending.pop(0)
+            cmd = [hipcc()] + cflags + ['-I', INCLUDE, '-c', src, '-o', _obj(src)]
+            if verbose:
+                print(' '.join(cmd))
+            procs.append((src, subprocess.Popen(cmd)))
+        src, pr = procs.pop(0)
+        if pr.wait() != 0:
+            failed = True
+            print('hipcc failed on', src, file=sys.stderr)
+    if failed:
+        raise subprocess.CalledProcessError(1, 'hipcc')
+    cmd = [hipcc(), '-shared', '-fPIC', '--offload-arch=' + ARCH, '-o', LIB] + \
+        [_obj(s) for s in sources()]
     if verbose:
         print(' '.join(cmd))
     subprocess.check_call(cmd)

@@ -6,6 +6,7 @@ import ctypes
 import torch
 
 from . import _lib, lss_prepare
+from .ops.bev_pool_v2 import bev_pool as _bp
 from .ops.bev_pool_v2.bev_pool import mark_sorted
 
 _F3 = ctypes.c_float * 3
@@ -142,7 +143,7 @@ def _finish(pre):
     # grid by construction
     mark_sorted(starts, 0, pre.batch * pre.vpb - 1)
     if pre.plan is not None:
-        starts._veon_plan = (pre.plan, pre.batch, pre.vpb)
+        _bp._cache_put(starts, rb, '_veon_plan', (pre.batch, pre.vpb), pre.plan)
     return (rb, pre.ranks_depth[:kept], pre.ranks_feat[:kept], starts,
             pre.interval_lengths[:n_int])
 

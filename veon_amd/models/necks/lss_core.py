@@ -119,8 +119,9 @@ class LSSCore(_Base):
         self.interval_lengths = interval_lengths.int().contiguous()
         starts = interval_starts.int().contiguous()
         tag = getattr(interval_starts, '_veon_sorted', None)
-        if tag is not None:
-            starts._veon_sorted = tag
+        if starts is not interval_starts and tag is not None and tag[0] \
+                and tag[3] == interval_starts._version:
+            _bp.mark_sorted(starts, tag[1], tag[2])
         self.interval_starts = starts
         B = coor.shape[0]
         vpb = int(self.grid_size[2]) * int(self.grid_size[1]) * \

@@ -25,31 +25,74 @@ __all__ = ['bev_pool_v2', 'TRTBEVPoolv2', 'QuickCumsumCuda']
 
 
 def mark_sorted(interval_starts, first_rank, last_rank):
-    """Tag produced-by-prepare interval arrays so the op never has to sync."""
-    interval_starts._veon_sorted = (True, int(first_rank), int(last_rank))
+    """Tag produced-by-prepare interval arrays (ascending voxel ranks, intervals
+    tiling the point arrays) so the op never has to sync.  The tag carries the
+    tensor's version counter: an in-place update of the tensor voids it."""
+    interval_starts._veon_sorted = (True, int(first_rank), int(last_rank),
+                                    interval_starts._version, None, None)
     return interval_starts
 
 
-def _sorted_info(ranks_bev, interval_starts):
-    """(sorted?, first_rank, last_rank) of the interval keys.  Cached on the
-    tensor object; computing it costs one host sync, once per tensor."""
+def _sorted_info(ranks_bev, interval_starts, interval_lengths=None):
+    """(fusable?, first_rank, last_rank) of the interval keys.  Fusable = keys
+    strictly ascending AND the intervals tile the point arrays (starts[0] == 0,
+    starts[i+1] == starts[i] + lengths[i], last end == P): the fused kernels
+    derive every length from the next start, the reference kernel reads
+    interval_lengths (bev_pool_cuda.cu:35), and the two agree exactly then.
+    Cached on the tensor object together with the version counters of the
+    tensors it was computed from; computing it costs one host sync."""
     tag = getattr(interval_starts, '_veon_sorted', None)
+    if tag is not None:
+        vs, vb, vl = tag[3], tag[4], tag[5]
+        if (vs != interval_starts._version
+                or (vb is not None and vb != ranks_bev._version)
+                or (vl is not None and interval_lengths is not None
+                    and vl != interval_lengths._version)):
+            tag = None
     if tag is None:
         if interval_starts.numel() == 0:
             tag = (True, 0, -1)
         else:
-            keys = ranks_bev[interval_starts.long()]
-            ok = True
+            starts = interval_starts.long()
+            keys = ranks_bev[starts]
+            ok = torch.ones((), dtype=torch.bool, device=starts.device)
             if keys.numel() > 1:
-                ok = bool((keys[1:] > keys[:-1]).all().item())
-            tag = (ok, int(keys[0].item()), int(keys[-1].item()))
+                ok = ok & (keys[1:] > keys[:-1]).all()
+            ok = ok & (starts[0] == 0)
+            if interval_lengths is not None:
+                lens = interval_lengths.long()
+                if lens.numel() != starts.numel():
+                    ok = ok & False
+                else:
+                    ok = ok & (starts[1:] == starts[:-1] + lens[:-1]).all()
+                    ok = ok & (starts[-1] + lens[-1] == ranks_bev.numel())
+            res = torch.stack([ok.long(), keys[0].long(), keys[-1].long()]).tolist()
+            tag = (bool(res[0]), int(res[1]), int(res[2]))
+        tag = tag + (interval_starts._version, ranks_bev._version,
+                     None if interval_lengths is None else interval_lengths._version)
         interval_starts._veon_sorted = tag
-    return tag
+    return tag[:3]
 
 
-def _can_fuse(ranks_bev, interval_starts, n_voxels):
-    ok, first, last = _sorted_info(ranks_bev, interval_starts)
+def _can_fuse(ranks_bev, interval_starts, n_voxels, interval_lengths=None):
+    ok, first, last = _sorted_info(ranks_bev, interval_starts, interval_lengths)
     return ok and first >= 0 and last < n_voxels
+
+
+def _cache_get(interval_starts, ranks_bev, name, key):
+    """Index structure `name` cached on interval_starts for `key`, or None when
+    absent or computed from other contents (version counters moved)."""
+    ent = getattr(interval_starts, name, None)
+    if ent is None or ent[1] != key:
+        return None
+    if ent[2] != (interval_starts._version, ranks_bev._version):
+        return None
+    return ent[0]
+
+
+def _cache_put(interval_starts, ranks_bev, name, key, value):
+    setattr(interval_starts, name,
+            (value, key, (interval_starts._version, ranks_bev._version)))
 
 
 _HALF = (torch.float16, torch.bfloat16)
@@ -99,9 +142,7 @@ def _inference_feat(feat, *others):
 def _prep_inputs(depth, feat, ranks_depth, ranks_feat, ranks_bev,
                  interval_starts, interval_lengths):
     # casts of bev_pool.py:19-25 (no-ops for what the prepare produces)
-    tag = getattr(interval_starts, '_veon_sorted', None)
-    plan = getattr(interval_starts, '_veon_plan', None)
-    def as_(t, dtype):   # the casts are no-ops for what the prepare produces
+    def as_(t, dtype):
         return t if (t.dtype == dtype and t.is_contiguous()) else t.contiguous().to(dtype)
     depth = as_(depth, torch.float32)
     feat = _inference_feat(feat, depth)
@@ -109,12 +150,12 @@ def _prep_inputs(depth, feat, ranks_depth, ranks_feat, ranks_bev,
     ranks_depth = as_(ranks_depth, torch.int32)
     ranks_feat = as_(ranks_feat, torch.int32)
     interval_lengths = as_(interval_lengths, torch.int32)
-    interval_starts = as_(interval_starts, torch.int32)
-    if tag is not None:
-        interval_starts._veon_sorted = tag
-    if plan is not None:
-        interval_starts._veon_plan = plan
-    return (depth, feat, ranks_depth, ranks_feat, ranks_bev, interval_starts,
+    starts = as_(interval_starts, torch.int32)
+    if starts is not interval_starts:
+        tag = getattr(interval_starts, '_veon_sorted', None)
+        if tag is not None and tag[3] == interval_starts._version and tag[4] is None:
+            mark_sorted(starts, tag[1], tag[2])   # a cast copy of trusted arrays
+    return (depth, feat, ranks_depth, ranks_feat, ranks_bev, starts,
             interval_lengths)
 
 
@@ -135,8 +176,110 @@ def build_plan(ranks_bev, interval_starts, batch, voxels_per_batch,
             _lib.ptr(counts), _lib.ptr(plan), _lib.stream_ptr(dev))
     _lib.check(st, 'veon_bev_pool_plan')
     if attach:
-        interval_starts._veon_plan = (plan, batch, voxels_per_batch)
+        _cache_put(interval_starts, ranks_bev, '_veon_plan', (batch, voxels_per_batch), plan)
     return plan
+
+
+def build_voxel_table(ranks_bev, interval_starts, batch, voxels_per_batch,
+                      attach=True, counts=None):
+    """Dense voxel table of the row kernels (include/veon_hip.h
+    ``veon_bev_pool_voxel_table``): vstart[v] = first point of voxel v in the
+    rank-sorted arrays, B*vpb + 1 entries."""
+    dev = _lib.require_device(ranks_bev, interval_starts)
+    L = _lib.lib()
+    vstart = torch.empty(L.veon_bev_pool_voxel_table_ints(batch, voxels_per_batch),
+                         dtype=torch.int32, device=dev)
+    with _lib.on_device(dev):
+        st = L.veon_bev_pool_voxel_table(
+            interval_starts.numel(), ranks_bev.numel(), batch, voxels_per_batch,
+            _lib.ptr(ranks_bev), _lib.ptr(interval_starts), _lib.ptr(counts),
+            _lib.ptr(vstart), _lib.stream_ptr(dev))
+    _lib.check(st, 'veon_bev_pool_voxel_table')
+    if attach:
+        _cache_put(interval_starts, ranks_bev, '_veon_vstart', (batch, voxels_per_batch),
+                   vstart)
+    return vstart
+
+
+def _voxel_table(ranks_bev, interval_starts, batch, vpb):
+    vstart = _cache_get(interval_starts, ranks_bev, '_veon_vstart', (batch, vpb))
+    if vstart is None:
+        vstart = build_voxel_table(ranks_bev, interval_starts, batch, vpb)
+    return vstart
+
+
+# Row kernels (csrc/bev_pool_rows.hip) take over from the slab kernels at this
+# channel count: one feature row is then >= 512 bytes and a workgroup reads it
+# once, full width (measured on MI355X: tools/kbench.py).
+ROWS_MIN_C = 128
+
+
+# the row kernels' optional depth pre-sort (one dependent load level less per wave)
+ROWS_SORT_DEPTH = True
+
+
+def _dsort_ws(ranks_depth, sort_depth):
+    if sort_depth is None:
+        sort_depth = ROWS_SORT_DEPTH
+    if not sort_depth or ranks_depth.numel() == 0:
+        return None
+    return torch.empty(ranks_depth.numel(), dtype=torch.float32, device=ranks_depth.device)
+
+
+def rows_forward(depth, feat, ranks_depth, ranks_feat, vstart, bev_feat_shape,
+                 out=None, variant=0, sort_depth=None):
+    """(B,C,Z,Y,X) fp32 volume by the row kernel, from the dense voxel table."""
+    B, Z, Y, X, C = [int(s) for s in bev_feat_shape]
+    dev = _lib.require_device(depth, feat, ranks_depth, ranks_feat, vstart)
+    if vstart.numel() != B * Z * Y * X + 1:
+        raise _lib.VeonHipError('voxel table does not match bev_feat_shape')
+    if out is None:
+        out = torch.empty((B, C, Z, Y, X), dtype=torch.float32, device=dev)
+    elif (tuple(out.shape) != (B, C, Z, Y, X) or out.dtype != torch.float32
+          or not out.is_contiguous() or out.device != dev):
+        raise _lib.VeonHipError('out must be a contiguous fp32 (B,C,Z,Y,X) tensor')
+    ws = _dsort_ws(ranks_depth, sort_depth)
+    with _lib.on_device(dev):
+        st = _lib.lib().veon_bev_pool_v2_fwd_rows(
+            C, B, Z * Y * X, _lib.ptr(depth), _lib.ptr(feat), _feat_code(feat),
+            _lib.ptr(ranks_depth), _lib.ptr(ranks_feat), _lib.ptr(vstart),
+            _lib.ptr(ws), _lib.ptr(out), 0, variant, _lib.stream_ptr(dev))
+    _lib.check(st, 'veon_bev_pool_v2_fwd_rows')
+    return out
+
+
+def rows_maxpool(depth, feat, ranks_depth, ranks_feat, vstart, bev_feat_shape, ds,
+                 out_volume=None, sort_depth=None):
+    """Pool + (2,2,2) block max by the row kernel: (B,C,Z/2,Y/2,X/2) fp32, or the
+    Conv3d body's padded bf16 input when ``out_volume`` is given."""
+    B, Z, Y, X, C = [int(s) for s in bev_feat_shape]
+    dz, dy, dx = [int(v) for v in ds]
+    dev = _lib.require_device(depth, feat, ranks_depth, ranks_feat, vstart)
+    if vstart.numel() != B * Z * Y * X + 1:
+        raise _lib.VeonHipError('voxel table does not match bev_feat_shape')
+    if out_volume is not None:
+        if out_volume.shape != (B, C, Z // dz, Y // dy, X // dx):
+            raise _lib.VeonHipError('out_volume shape %r does not match the pooled '
+                                    'volume' % (out_volume.shape,))
+        target, padded, ret = out_volume.rows, 1, out_volume
+    else:
+        ret = torch.empty((B, C, Z // dz, Y // dy, X // dx), dtype=torch.float32,
+                          device=dev)
+        target, padded = ret, 0
+    ws = _dsort_ws(ranks_depth, sort_depth)
+    with _lib.on_device(dev):
+        st = _lib.lib().veon_bev_pool_v2_fwd_rows_maxpool(
+            C, B, Z, Y, X, dz, dy, dx, _lib.ptr(depth), _lib.ptr(feat),
+            _feat_code(feat), _lib.ptr(ranks_depth), _lib.ptr(ranks_feat),
+            _lib.ptr(vstart), _lib.ptr(ws), _lib.ptr(target), padded, _lib.stream_ptr(dev))
+    _lib.check(st, 'veon_bev_pool_v2_fwd_rows_maxpool')
+    return ret
+
+
+def _rows_ok(C, ds=None):
+    if C < ROWS_MIN_C or C % 4:
+        return False
+    return ds is None or tuple(int(v) for v in ds) == (2, 2, 2)
 
 
 def _fused_forward(depth, feat, ranks_depth, ranks_feat, ranks_bev,
@@ -155,10 +298,12 @@ def _fused_forward(depth, feat, ranks_depth, ranks_feat, ranks_bev,
         out = torch.empty((B, C, Z, Y, X), dtype=torch.float32, device=dev)
     else:
         out = torch.empty((B, Z, Y, X, C), dtype=torch.float32, device=dev)
-    cached = getattr(interval_starts, '_veon_plan', None)
-    if cached is not None and cached[1] == B and cached[2] == Z * Y * X:
-        plan = cached[0]
-    else:
+    if layout == _lib.LAYOUT_BCZYX and _rows_ok(C):
+        vstart = _voxel_table(ranks_bev, interval_starts, B, Z * Y * X)
+        return rows_forward(depth, feat, ranks_depth, ranks_feat, vstart,
+                            bev_feat_shape, out=out)
+    plan = _cache_get(interval_starts, ranks_bev, '_veon_plan', (B, Z * Y * X))
+    if plan is None:
         plan = build_plan(ranks_bev, interval_starts, B, Z * Y * X,
                           attach=False)
     with _lib.on_device(dev):
@@ -208,7 +353,7 @@ class QuickCumsumCuda(torch.autograd.Function):
                                           interval_lengths)
         B, Z, Y, X, C = [int(s) for s in bev_feat_shape]
         feat = feat.float()
-        if _can_fuse(ranks_bev, interval_starts, B * Z * Y * X):
+        if _can_fuse(ranks_bev, interval_starts, B * Z * Y * X, interval_lengths):
             out = _fused_forward(depth, feat, ranks_depth, ranks_feat,
                                  ranks_bev, interval_starts, interval_lengths,
                                  bev_feat_shape, _lib.LAYOUT_BZYXC)
@@ -263,7 +408,7 @@ def bev_pool_v2(depth, feat, ranks_depth, ranks_feat, ranks_bev,
                                       ranks_bev, interval_starts,
                                       interval_lengths)
     B, Z, Y, X, C = [int(s) for s in bev_feat_shape]
-    if _can_fuse(ranks_bev, interval_starts, B * Z * Y * X):
+    if _can_fuse(ranks_bev, interval_starts, B * Z * Y * X, interval_lengths):
         no_grad = not (torch.is_grad_enabled()
                        and (depth.requires_grad or feat.requires_grad))
         if feat.dtype in _HALF or (out is not None and no_grad):
@@ -329,7 +474,8 @@ def build_row_table(ranks_bev, interval_starts, batch, voxels_per_batch,
             _lib.stream_ptr(dev))
     _lib.check(st, 'veon_bev_pool_row_table')
     if attach:
-        interval_starts._veon_rows = (table, batch, voxels_per_batch, row_voxels)
+        _cache_put(interval_starts, ranks_bev, '_veon_rows',
+                   (batch, voxels_per_batch, row_voxels), table)
     return table
 
 
@@ -350,10 +496,14 @@ def bev_pool_v2_maxpool(depth, feat, ranks_depth, ranks_feat, ranks_bev,
     dz, dy, dx = [int(v) for v in ds]
     dev = _lib.require_device(depth, feat, ranks_depth, ranks_feat, ranks_bev,
                               interval_starts, interval_lengths)
-    rows = getattr(interval_starts, '_veon_rows', None)
-    if counts is None and rows is not None and rows[1:] == (B, Z * Y * X, X):
-        table = rows[0]
-    else:
+    if counts is None and _rows_ok(C, ds):
+        vstart = _voxel_table(ranks_bev, interval_starts, B, Z * Y * X)
+        return rows_maxpool(depth, feat, ranks_depth, ranks_feat, vstart,
+                            bev_feat_shape, ds, out_volume=out_volume)
+    table = None
+    if counts is None:
+        table = _cache_get(interval_starts, ranks_bev, '_veon_rows', (B, Z * Y * X, X))
+    if table is None:
         table = build_row_table(ranks_bev, interval_starts, B, Z * Y * X, X,
                                 counts=counts, attach=False)
     if out_volume is not None:
