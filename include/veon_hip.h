@@ -163,11 +163,14 @@ int veon_bev_pool_v2_fwd_maxpool(int c, int n_intervals, int batch, int Z, int Y
  *   out_padded_bf16 = 0: out is (B,C,Z/2,Y/2,X/2) fp32;  1: out is the interior
  *   of the Conv3d body's zero-padded channels-last bf16 grid (as
  *   veon_bev_pool_v2_fwd_maxpool_padded).  c % 4 == 0.
- * depth_sorted_ws (optional, one float per kept point, i.e. vstart's last entry;
- *   the capacity of ranks_depth is always enough): when given, a pre-pass writes
- *   depth[ranks_depth[q]] there and the kernels read it linearly -- one dependent
- *   load level less in every wave (same values, so bit-identical results).
+ * feat_elems: number of elements of `feat` (rows * c); must be < 2^31 (row offsets
+ *   are 32-bit inside the kernels; every ranks_feat value must be a valid row).
  */
+/* experiment knob of tools/poolbench.py (ablations); 0 = production */
+void veon_pool_debug_set(int flags);
+/* tuning knobs of the row max-pool kernel (0 = built-in default): worker
+ * workgroups, longest cold list, longest warm list */
+void veon_pool_tune_set(int workers, int cold_max, int warm_max);
 int64_t veon_bev_pool_voxel_table_ints(int batch, int64_t voxels_per_batch);
 int veon_bev_pool_voxel_table(int n_intervals, int n_points, int batch,
                               int64_t voxels_per_batch, const int *ranks_bev,
@@ -176,14 +179,14 @@ int veon_bev_pool_voxel_table(int n_intervals, int n_points, int batch,
 int veon_bev_pool_v2_fwd_rows(int c, int batch, int64_t voxels_per_batch,
                               const float *depth, const void *feat, int feat_dtype,
                               const int *ranks_depth, const int *ranks_feat,
-                              const int *vstart, float *depth_sorted_ws, float *out,
-                              int64_t plane_stride, int variant, void *stream);
+                              const int *vstart, float *out, int64_t plane_stride,
+                              int64_t feat_elems, int variant, void *stream);
 int veon_bev_pool_v2_fwd_rows_maxpool(int c, int batch, int Z, int Y, int X, int dz,
                                       int dy, int dx, const float *depth,
                                       const void *feat, int feat_dtype,
                                       const int *ranks_depth, const int *ranks_feat,
-                                      const int *vstart, float *depth_sorted_ws,
-                                      void *out, int out_padded_bf16, void *stream);
+                                      const int *vstart, void *out, int out_padded_bf16,
+                                      int64_t feat_elems, void *stream);
 
 /*
  * Half-precision feature rows.  QuickCumsumCuda.forward widens feat to fp32
@@ -275,6 +278,32 @@ int veon_lidar_coor(int B, int N, int D, int H, int W, const float *xs,
  */
 int64_t veon_lss_prepare_workspace_bytes(int64_t num_points,
                                          int64_t num_voxels_total);
+/*
+ * The same prepare straight from the reference's per-camera tensors
+ * (get_lidar_coor's arguments, view_transformer_raw.py:121-158: sensor2ego
+ * (B,N,4,4), cam2imgs / post_rots (B,N,3,3), post_trans (B,N,3), bda (B,3,3)): the
+ * camera algebra of veon_camera_matrices runs inside the first kernel (one launch
+ * less, same arithmetic), five launches in all.  Extras for a steady-state,
+ * hipGraph-captured caller:
+ *   vstart (optional, B*voxels_per_batch + 1 int32): the dense voxel table of the
+ *     row pool kernels (veon_bev_pool_voxel_table's output) -- it is the counting
+ *     sort's own scan, so it costs nothing;
+ *   hist_is_zero = 1: the caller zeroed the WHOLE workspace once (at allocation)
+ *     and has only used it for completed calls of this function since: every
+ *     call leaves the histogram zeroed again, so no memset node is needed.
+ *     With 0 the histogram is cleared first (hipMemsetAsync).
+ */
+int veon_lss_prepare_cameras(int B, int N, int D, int H, int W, const float *xs,
+                             const float *ys, const float *ds,
+                             const float *sensor2ego, const float *cam2imgs,
+                             const float *post_rots, const float *post_trans,
+                             const float *bda, const float *grid_lower,
+                             const float *grid_interval, const float *grid_size,
+                             int64_t voxels_per_batch, void *workspace,
+                             int64_t workspace_bytes, int hist_is_zero,
+                             int *ranks_bev, int *ranks_depth, int *ranks_feat,
+                             int *interval_starts, int *interval_lengths, int *plan,
+                             int *vstart, int *counts, void *stream);
 int veon_lss_prepare(int B, int N, int D, int H, int W, const float *coor,
                      const float *xs, const float *ys, const float *ds,
                      const float *post_rots_inv, const float *post_trans,

@@ -90,8 +90,7 @@ def test_rows_forward_random_structures_bit_exact(C, dtype):
         for variant in range(4):
             junk = torch.full((int(np.prod(shape)),), float('nan'), device=DEV)
             del junk
-            got = bp.rows_forward(dev(depth), feat_d, rd, rf, vs, shape, variant=variant,
-                                  sort_depth=bool((variant + rep) & 1))
+            got = bp.rows_forward(dev(depth), feat_d, rd, rf, vs, shape, variant=variant)
             assert np.array_equal(got.cpu().numpy(), want), (rep, variant)
 
 
@@ -107,14 +106,12 @@ def test_rows_maxpool_random_structures_bit_exact(C, dtype):
         rb, rd, rf, st, ln = (dev(a) for a in ranks)
         B, Z, Y, X, _ = shape
         vs = bp.build_voxel_table(rb, st, B, Z * Y * X, attach=False)
-        got = bp.rows_maxpool(dev(depth), feat_d, rd, rf, vs, shape, (2, 2, 2),
-                              sort_depth=bool(rep & 1))
+        got = bp.rows_maxpool(dev(depth), feat_d, rd, rf, vs, shape, (2, 2, 2))
         assert np.array_equal(got.cpu().numpy(), want), rep
         # padded bf16 channels-last output == bf16 rounding of the fp32 result
         vol = conv3d_ops.PaddedVolume(B, C, Z // 2, Y // 2, X // 2, DEV)
         vol.storage.fill_(7.0)          # interior must be overwritten everywhere
-        bp.rows_maxpool(dev(depth), feat_d, rd, rf, vs, shape, (2, 2, 2), out_volume=vol,
-                        sort_depth=not (rep & 1))
+        bp.rows_maxpool(dev(depth), feat_d, rd, rf, vs, shape, (2, 2, 2), out_volume=vol)
         inner = vol.interior().permute(0, 4, 1, 2, 3).float().cpu().numpy()
         assert np.array_equal(inner, torch.from_numpy(want).bfloat16().float().numpy())
 

@@ -195,7 +195,10 @@ def test_temporal_decoder_fast_path_agrees_with_modules():
         fast = net(sem_feat, clip, [t['supp']], t['metric'], metas, [prev])
         ran = {k for k, v in _lib.CALLS.items() if v > before.get(k, 0)}
         assert {'veon_volume_warp_bf16', 'veon_deform_attention_bf16',
-                'veon_conv3d_k3_bf16', 'veon_bev_pool_v2_fwd_maxpool_padded'} <= ran, ran
+                'veon_conv3d_k3_bf16'} <= ran, ran
+        # the fused pool + max-pool: row kernel from 64 channels on, slab kernel below
+        assert {'veon_bev_pool_v2_fwd_maxpool_padded',
+                'veon_bev_pool_v2_fwd_rows_maxpool'} & ran, ran
         net.use_hip = False
         for m in (net.occupancy_pred, net.feat_pred):
             m._hip_ok = lambda x: False

@@ -81,22 +81,22 @@ def main():
                           _lib.ptr(vol.rows if padded else mp), s), 'slab_mp')
         return run
 
-    dws = torch.empty(rd.numel(), dtype=torch.float32, device=dev)
-
     def rows_cf(f, variant, ds=True):
         def run():
             _lib.check(L.veon_bev_pool_v2_fwd_rows(
                 C, 1, vpb, _lib.ptr(depth), _lib.ptr(f), bp._feat_code(f), _lib.ptr(rd),
-                _lib.ptr(rf), _lib.ptr(vs), _lib.ptr(dws if ds else None), _lib.ptr(out),
-                0, variant, s), 'rows_cf')
+                _lib.ptr(rf), _lib.ptr(vs), _lib.ptr(out), 0, f.numel(), variant, s), 'rows_cf')
         return run
 
-    def rows_mp(f, padded, ds=True):
+    def rows_mp(f, padded, ds=True, dbg=0):
         def run():
+            L.veon_pool_debug_set(dbg)
             _lib.check(L.veon_bev_pool_v2_fwd_rows_maxpool(
                 C, 1, Z, Y, X, 2, 2, 2, _lib.ptr(depth), _lib.ptr(f), bp._feat_code(f),
-                _lib.ptr(rd), _lib.ptr(rf), _lib.ptr(vs), _lib.ptr(dws if ds else None),
-                _lib.ptr(vol.rows if padded else mp), 1 if padded else 0, s), 'rows_mp')
+                _lib.ptr(rd), _lib.ptr(rf), _lib.ptr(vs),
+                _lib.ptr(vol.rows if padded else mp), 1 if padded else 0, f.numel(), s),
+                'rows_mp')
+            L.veon_pool_debug_set(0)
         return run
 
     cases = [('fill(torch)', out.zero_, alg, None)]
@@ -104,16 +104,20 @@ def main():
               ('slab_cf bf16', slab_cf(feat_b), alg, 'cfb')]
     for v in range(4):
         cases.append(('rows_cf f32 v%d' % v, rows_cf(feat, v), alg, 'cf32'))
-    cases.append(('rows_cf f32 v0 nods', rows_cf(feat, 0, False), alg, 'cf32'))
-    cases.append(('rows_cf f32 v1 nods', rows_cf(feat, 1, False), alg, 'cf32'))
     cases.append(('rows_cf bf16 v0', rows_cf(feat_b, 0), alg, 'cfb'))
     cases.append(('rows_cf bf16 v1', rows_cf(feat_b, 1), alg, 'cfb'))
     cases += [('slab_mp f32', slab_mp(feat, False), alg_mp, 'mp32'),
               ('rows_mp f32', rows_mp(feat, False), alg_mp, 'mp32'),
-              ('rows_mp f32 nods', rows_mp(feat, False, False), alg_mp, 'mp32'),
               ('slab_mp bf16 padded', slab_mp(feat_b, True), alg_mp, 'mpb'),
               ('rows_mp bf16 padded', rows_mp(feat_b, True), alg_mp, 'mpb'),
-              ('rows_mp bf16 pad nods', rows_mp(feat_b, True, False), alg_mp, 'mpb')]
+              ('rows_mp bf16 ABL cold only', rows_mp(feat_b, True, False, 1), alg_mp, None),
+              ('rows_mp bf16 ABL workers only', rows_mp(feat_b, True, False, 2), alg_mp, None),
+              ('rows_mp bf16 ABL -warm', rows_mp(feat_b, True, False, 4), alg_mp, None),
+              ('rows_mp bf16 ABL -hot', rows_mp(feat_b, True, False, 8), alg_mp, None),
+              ('rows_mp bf16 ABL onlyhot', rows_mp(feat_b, True, False, 6), alg_mp, None),
+              ('rows_mp bf16 ABL onlywarm', rows_mp(feat_b, True, False, 10), alg_mp, None),
+              ('rows_mp f32 ABL cold only', rows_mp(feat, False, False, 1), alg_mp, None),
+              ('rows_mp f32 ABL workers only', rows_mp(feat, False, False, 2), alg_mp, None)]
     if only:
         cases = [c for c in cases if only in c[0]]
     # parity between the two families (the oracle comparison lives in tests/)

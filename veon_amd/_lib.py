@@ -48,12 +48,14 @@ _SIGNATURES = {
     'veon_bev_pool_v2_fwd_maxpool_ex': (_ci, [_ci] * 9 + [_vp, _vp, _ci] + [_vp] * 7 + [_vp]),
     'veon_bev_pool_v2_fwd_maxpool_padded': (_ci, [_ci] * 9 + [_vp, _vp, _ci] + [_vp] * 7 + [_vp]),
     'veon_bev_pool_tile_voxels': (_ci, []),
+    'veon_pool_debug_set': (None, [_ci]),
+    'veon_pool_tune_set': (None, [_ci, _ci, _ci]),
     'veon_bev_pool_voxel_table_ints': (_i64, [_ci, _i64]),
     'veon_bev_pool_voxel_table': (_ci, [_ci, _ci, _ci, _i64, _vp, _vp, _vp, _vp, _vp]),
-    'veon_bev_pool_v2_fwd_rows': (_ci, [_ci, _ci, _i64, _vp, _vp, _ci, _vp, _vp, _vp, _vp, _vp,
-                                        _i64, _ci, _vp]),
+    'veon_bev_pool_v2_fwd_rows': (_ci, [_ci, _ci, _i64, _vp, _vp, _ci, _vp, _vp, _vp, _vp,
+                                        _i64, _i64, _ci, _vp]),
     'veon_bev_pool_v2_fwd_rows_maxpool': (_ci, [_ci] * 8 + [_vp, _vp, _ci, _vp, _vp, _vp, _vp,
-                                                _vp, _ci, _vp]),
+                                                _ci, _i64, _vp]),
     'veon_bev_pool_plan_ints': (_i64, [_ci, _i64]),
     'veon_bev_pool_plan': (_ci, [_ci, _ci, _ci, _i64, _vp, _vp, _vp, _vp, _vp]),
     'veon_bev_pool_row_table': (_ci, [_ci, _ci, _ci, _i64, _ci, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -88,6 +90,8 @@ _SIGNATURES = {
     'veon_camera_matrices': (_ci, [_ci] + [_vp] * 6 + [_vp]),
     'veon_lidar_coor': (_ci, [_ci] * 5 + [_vp] * 9 + [_vp]),
     'veon_lss_prepare_workspace_bytes': (_i64, [_i64, _i64]),
+    'veon_lss_prepare_cameras': (_ci, [_ci] * 5 + [_vp] * 8 + [_vp] * 3 + [_i64, _vp, _i64, _ci]
+                                 + [_vp] * 8 + [_vp]),
     'veon_lss_prepare': (_ci, [_ci] * 5 + [_vp] * 9 + [_vp] * 3 + [_i64, _vp, _i64]
                          + [_vp] * 7 + [_vp]),
 }

@@ -8,9 +8,12 @@
 //
 //   k_voxel_keys   one lane per frustum point: coordinates (optional output),
 //                  voxel, in-grid test, float32 rank -> key; histogram by atomics
-//   k_scan_*       exclusive scan of the histogram over all voxels (3 kernels),
-//                  emits interval_starts / interval_lengths, counts and the
-//                  64-voxel tile plan of the fused pool kernels
+//   k_scan_*       exclusive scan of the histogram over all voxels (2 kernels:
+//                  per-block sums, then every block adds up the sums before it
+//                  and emits): the dense voxel table vstart (= the row pool
+//                  kernels' index), interval_starts / interval_lengths, counts,
+//                  the 64-voxel tile plan of the slab pool kernels; leaves the
+//                  histogram zeroed for the next call (no memset node)
 //   k_scatter      points -> their voxel's slot range (slot = the arrival index
 //                  the histogram atomic returned; no second atomic pass)
 //   k_rank_in_bin  deterministic stable order inside every interval
@@ -160,18 +163,48 @@ __device__ __forceinline__ int voxel_key(const GridF& gr, const float* c,
 // grid = (points of one camera / kBlock, B*N cameras): the camera index is
 // workgroup-uniform, so the 3x3 matrices come in by scalar loads.  The
 // returning histogram atomic doubles as the point's arrival slot in its voxel.
-template <bool FROM_COOR>
+struct CameraRaw {  // FROM == 2: the reference's per-camera inputs
+  const float* sensor2ego;  // [B,N,4,4]
+  const float* cam2imgs;    // [B,N,3,3]
+  const float* post_rots;   // [B,N,3,3]
+};
+
+// FROM: 0 = geometry from prepared matrices, 1 = given coordinates, 2 = geometry
+// from the raw camera tensors (the algebra of k_camera_matrices runs once per
+// workgroup into LDS: one launch less, same arithmetic, same bits).
+template <int FROM>
 __global__ __launch_bounds__(kBlock) void k_voxel_keys(
-    Geometry g, const float* __restrict__ coor, GridF gr, int N, int D, int H,
-    int W, int64_t n_bins, int* __restrict__ keys, int* __restrict__ slots,
+    Geometry g, CameraRaw cr, const float* __restrict__ coor, GridF gr, int N, int D,
+    int H, int W, int64_t n_bins, int* __restrict__ keys, int* __restrict__ slots,
     int* __restrict__ hist) {
+  __shared__ float cam[21];  // post_rots_inv[9], combine[9], trans[3]
   const int bn = blockIdx.y;
+  if constexpr (FROM == 2) {
+    if (threadIdx.x == 0) {
+      float pri[9], kin[9];
+      inv3_f64(cr.post_rots + bn * 9, pri);
+      inv3_f64(cr.cam2imgs + bn * 9, kin);
+      const float* s = cr.sensor2ego + bn * 16;
+      for (int r = 0; r < 3; ++r) {
+        for (int cidx = 0; cidx < 3; ++cidx) {
+          float acc = 0.f;
+          acc = acc + s[r * 4 + 0] * kin[0 * 3 + cidx];
+          acc = acc + s[r * 4 + 1] * kin[1 * 3 + cidx];
+          acc = acc + s[r * 4 + 2] * kin[2 * 3 + cidx];
+          cam[9 + r * 3 + cidx] = acc;
+        }
+        cam[18 + r] = s[r * 4 + 3];
+      }
+      for (int k = 0; k < 9; ++k) cam[k] = pri[k];
+    }
+    __syncthreads();
+  }
   const int dhw = D * H * W;
   const int i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= dhw) return;
   const int64_t p = (int64_t)bn * dhw + i;
   float c[3];
-  if (FROM_COOR) {
+  if constexpr (FROM == 1) {
     c[0] = coor[p * 3 + 0];
     c[1] = coor[p * 3 + 1];
     c[2] = coor[p * 3 + 2];
@@ -179,7 +212,23 @@ __global__ __launch_bounds__(kBlock) void k_voxel_keys(
     const int w = i % W;
     const int h = (i / W) % H;
     const int d = i / (W * H);
-    point_coor(g, bn, bn / N, d, h, w, c);
+    if constexpr (FROM == 2) {
+      // point_coor with this camera's matrices from LDS
+      const float* pt = g.post_trans + bn * 3;
+      const float fx = g.xs[w] - pt[0];
+      const float fy = g.ys[h] - pt[1];
+      const float fz = g.ds[d] - pt[2];
+      float pp[3], q[3];
+      mat3_vec(cam, fx, fy, fz, pp);
+      const float cx = pp[0] * pp[2], cy = pp[1] * pp[2], cz = pp[2];
+      mat3_vec(cam + 9, cx, cy, cz, q);
+      q[0] += cam[18];
+      q[1] += cam[19];
+      q[2] += cam[20];
+      mat3_vec(g.bda + (bn / N) * 9, q[0], q[1], q[2], c);
+    } else {
+      point_coor(g, bn, bn / N, d, h, w, c);
+    }
   }
   int key = voxel_key(gr, c, bn / N);
   if (key >= n_bins) key = -1;  // cannot happen for consistent grids; be safe
@@ -227,48 +276,28 @@ __global__ __launch_bounds__(kBlock) void k_scan_reduce(
   if (threadIdx.x == 0) block_sums[blockIdx.x] = t;
 }
 
-// single block: exclusive scan of the block sums in place; totals -> counts
-__global__ __launch_bounds__(kBlock) void k_scan_blocks(
-    Pair* __restrict__ block_sums, int n_blocks, int* __restrict__ counts) {
-  __shared__ Pair sm[kBlock];
-  Pair carry{0, 0};
-  for (int base = 0; base < n_blocks; base += kBlock) {
-    const int i = base + threadIdx.x;
-    Pair v = i < n_blocks ? block_sums[i] : Pair{0, 0};
-    sm[threadIdx.x] = v;
-    __syncthreads();
-    // Hillis-Steele inclusive scan in LDS
-    for (int off = 1; off < kBlock; off <<= 1) {
-      Pair add{0, 0};
-      if (threadIdx.x >= off) add = sm[threadIdx.x - off];
-      __syncthreads();
-      sm[threadIdx.x].pts += add.pts;
-      sm[threadIdx.x].ivs += add.ivs;
-      __syncthreads();
-    }
-    const Pair incl = sm[threadIdx.x];
-    if (i < n_blocks)
-      block_sums[i] = Pair{carry.pts + incl.pts - v.pts, carry.ivs + incl.ivs - v.ivs};
-    const Pair tot = sm[kBlock - 1];
-    __syncthreads();
-    carry.pts += tot.pts;
-    carry.ivs += tot.ivs;
-  }
-  if (threadIdx.x == 0) {
-    counts[0] = carry.pts;  // P_kept
-    counts[1] = carry.ivs;  // n_intervals
-  }
-}
-
-// per block: local exclusive scan + block offset; writes bin_start (in place of
-// nothing: separate array), the interval arrays and the plan entries of the
-// block's 16 tiles.
+// per block: offset = sum of the block sums before this block (a few hundred
+// values, added up by the block itself: no separate single-block scan launch),
+// local exclusive scan, then: vstart (dense voxel table, n_bins + 1 entries), the
+// interval arrays, the plan entries of the block's 16 tiles, counts (last
+// block); the histogram is left zeroed.
 __global__ __launch_bounds__(kBlock) void k_scan_emit(
-    const int* __restrict__ hist, int64_t n_bins, const Pair* __restrict__ block_sums,
-    int* __restrict__ bin_start, int* __restrict__ interval_starts,
+    int* __restrict__ hist, int64_t n_bins, const Pair* __restrict__ block_sums,
+    int* __restrict__ vstart, int* __restrict__ interval_starts,
     int* __restrict__ interval_lengths, int4* __restrict__ plan,
-    int64_t vpb, int64_t tiles_per_batch) {
+    int64_t vpb, int64_t tiles_per_batch, int* __restrict__ counts) {
   __shared__ Pair sm[kBlock];
+  __shared__ Pair red[kBlock / 64];
+  __shared__ Pair boff_s;
+  {
+    Pair v{0, 0};
+    for (int i = threadIdx.x; i < (int)blockIdx.x; i += kBlock) {
+      v.pts += block_sums[i].pts;
+      v.ivs += block_sums[i].ivs;
+    }
+    const Pair t = block_reduce(v, red);
+    if (threadIdx.x == 0) boff_s = t;
+  }
   const int64_t base = (int64_t)blockIdx.x * kScanBlock + threadIdx.x * kScanItems;
   int c[kScanItems];
   Pair v{0, 0};
@@ -276,6 +305,7 @@ __global__ __launch_bounds__(kBlock) void k_scan_emit(
   for (int k = 0; k < kScanItems; ++k) {
     const int64_t i = base + k;
     c[k] = i < n_bins ? hist[i] : 0;
+    if (i < n_bins) hist[i] = 0;
     v.pts += c[k];
     v.ivs += c[k] > 0;
   }
@@ -289,14 +319,14 @@ __global__ __launch_bounds__(kBlock) void k_scan_emit(
     sm[threadIdx.x].ivs += add.ivs;
     __syncthreads();
   }
-  const Pair boff = block_sums[blockIdx.x];
+  const Pair boff = boff_s;
   Pair run{boff.pts + sm[threadIdx.x].pts - v.pts,
            boff.ivs + sm[threadIdx.x].ivs - v.ivs};
 #pragma unroll
   for (int k = 0; k < kScanItems; ++k) {
     const int64_t i = base + k;
     if (i < n_bins) {
-      bin_start[i] = run.pts;
+      vstart[i] = run.pts;
       if (c[k] > 0) {
         interval_starts[run.ivs] = run.pts;
         interval_lengths[run.ivs] = c[k];
@@ -304,6 +334,11 @@ __global__ __launch_bounds__(kBlock) void k_scan_emit(
     }
     run.pts += c[k];
     run.ivs += c[k] > 0;
+  }
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == kBlock - 1) {
+    counts[0] = run.pts;  // P_kept
+    counts[1] = run.ivs;  // n_intervals
+    vstart[n_bins] = run.pts;
   }
   // plan: tiles are 64 consecutive voxel ranks of ONE batch element.  When the
   // voxel count per batch is a multiple of 64 (and so of the scan block's tile
@@ -343,15 +378,15 @@ __global__ __launch_bounds__(kBlock) void k_scatter(
 // interval with a smaller index.  One lane per kept point.
 __global__ __launch_bounds__(kBlock) void k_rank_in_bin(
     const int* __restrict__ keys, const int* __restrict__ tmp_point,
-    const int* __restrict__ counts, const int* __restrict__ bin_start,
-    const int* __restrict__ hist, int D, int HW, int* __restrict__ ranks_bev,
+    const int* __restrict__ counts, const int* __restrict__ bin_start, int D, int HW,
+    int* __restrict__ ranks_bev,
     int* __restrict__ ranks_depth, int* __restrict__ ranks_feat) {
   const int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (q >= counts[0]) return;
   const int p = tmp_point[q];
   const int key = keys[p];
   const int start = bin_start[key];
-  const int len = hist[key];
+  const int len = bin_start[key + 1] - start;
   int rank = 0;
   for (int i = 0; i < len; ++i) rank += tmp_point[start + i] < p;
   const int slot = start + rank;
@@ -369,8 +404,8 @@ struct Workspace {
   int* keys;       // [P]
   int* slots;      // [P]  arrival index of the point inside its voxel
   int* tmp_point;  // [P]
-  int* hist;       // [n_bins]      (zeroed per call)
-  int* bin_start;  // [n_bins]
+  int* hist;       // [n_bins]      (zero on entry, left zero)
+  int* bin_start;  // [n_bins + 1]  (used when the caller passes no vstart)
   Pair* block_sums;  // [n_scan_blocks]
   int64_t bytes;
 };
@@ -390,7 +425,7 @@ inline Workspace carve(void* base, int64_t P, int64_t n_bins) {
   w.slots = reinterpret_cast<int*>(take(P * 4));
   w.tmp_point = reinterpret_cast<int*>(take(P * 4));
   w.hist = reinterpret_cast<int*>(take(n_bins * 4));
-  w.bin_start = reinterpret_cast<int*>(take(n_bins * 4));
+  w.bin_start = reinterpret_cast<int*>(take((n_bins + 1) * 4));
   const int64_t n_scan_blocks = (n_bins + kScanBlock - 1) / kScanBlock;
   w.block_sums = reinterpret_cast<Pair*>(take(n_scan_blocks * (int64_t)sizeof(Pair)));
   w.bytes = off;
@@ -440,28 +475,33 @@ int64_t veon_lss_prepare_workspace_bytes(int64_t num_points,
   return carve(nullptr, num_points, num_voxels_total).bytes;
 }
 
-int veon_lss_prepare(int B, int N, int D, int H, int W, const float* coor,
-                     const float* xs, const float* ys, const float* ds,
-                     const float* post_rots_inv, const float* post_trans,
-                     const float* combine, const float* trans, const float* bda,
-                     const float* grid_lower, const float* grid_interval,
-                     const float* grid_size, int64_t voxels_per_batch,
-                     void* workspace, int64_t workspace_bytes, int* ranks_bev,
-                     int* ranks_depth, int* ranks_feat, int* interval_starts,
-                     int* interval_lengths, int* plan, int* counts,
-                     void* stream) {
+static int prepare_impl(int B, int N, int D, int H, int W, const float* coor,
+                        const float* xs, const float* ys, const float* ds,
+                        const float* post_rots_inv, const float* post_trans,
+                        const float* combine, const float* trans, const float* bda,
+                        const float* sensor2ego, const float* cam2imgs,
+                        const float* post_rots, const float* grid_lower,
+                        const float* grid_interval, const float* grid_size,
+                        int64_t voxels_per_batch, void* workspace,
+                        int64_t workspace_bytes, int hist_is_zero, int* ranks_bev,
+                        int* ranks_depth, int* ranks_feat, int* interval_starts,
+                        int* interval_lengths, int* plan, int* vstart, int* counts,
+                        void* stream) {
   if (B <= 0 || N <= 0 || D <= 0 || H <= 0 || W <= 0 || voxels_per_batch <= 0)
     return VEON_ERR_BAD_ARG;
   if (!grid_lower || !grid_interval || !grid_size || !workspace || !ranks_bev ||
       !ranks_depth || !ranks_feat || !interval_starts || !interval_lengths ||
       !counts)
     return VEON_ERR_BAD_ARG;
-  if (!coor && (!xs || !ys || !ds || !post_rots_inv || !post_trans || !combine ||
-                !trans || !bda))
-    return VEON_ERR_BAD_ARG;
+  const bool raw = sensor2ego != nullptr;
+  if (!coor) {
+    if (!xs || !ys || !ds || !post_trans || !bda) return VEON_ERR_BAD_ARG;
+    if (raw ? (!cam2imgs || !post_rots) : (!post_rots_inv || !combine || !trans))
+      return VEON_ERR_BAD_ARG;
+  }
   const int64_t P = (int64_t)B * N * D * H * W;
   const int64_t n_bins = voxels_per_batch * B;
-  if (P > 0x7fffffffLL || n_bins > 0x7fffffffLL || B * N > 65535)
+  if (P > 0x7fffffffLL || n_bins > 0x7ffffffeLL || B * N > 65535)
     return VEON_ERR_BAD_ARG;
   // the plan emitted by the scan needs tiles aligned to the scan blocks
   if (plan && (voxels_per_batch % kTileV != 0)) return VEON_ERR_BAD_ARG;
@@ -476,33 +516,74 @@ int veon_lss_prepare(int B, int N, int D, int H, int W, const float* coor,
     gr.size[i] = grid_size[i];
   }
   Geometry g{xs, ys, ds, post_rots_inv, post_trans, combine, trans, bda};
-  if (hipMemsetAsync(w.hist, 0, (size_t)n_bins * 4, s) != hipSuccess)
+  CameraRaw cr{sensor2ego, cam2imgs, post_rots};
+  if (!hist_is_zero &&
+      hipMemsetAsync(w.hist, 0, (size_t)n_bins * 4, s) != hipSuccess)
     return VEON_ERR_LAUNCH;
+  int* table = vstart ? vstart : w.bin_start;
   const unsigned pb = (unsigned)((P + kBlock - 1) / kBlock);
   const int64_t dhw = (int64_t)D * H * W;
   const dim3 kgrid((unsigned)((dhw + kBlock - 1) / kBlock), (unsigned)(B * N));
   if (coor)
-    hipLaunchKernelGGL(k_voxel_keys<true>, kgrid, dim3(kBlock), 0, s, g, coor,
-                       gr, N, D, H, W, n_bins, w.keys, w.slots, w.hist);
+    hipLaunchKernelGGL(k_voxel_keys<1>, kgrid, dim3(kBlock), 0, s, g, cr, coor, gr, N,
+                       D, H, W, n_bins, w.keys, w.slots, w.hist);
+  else if (raw)
+    hipLaunchKernelGGL(k_voxel_keys<2>, kgrid, dim3(kBlock), 0, s, g, cr, coor, gr, N,
+                       D, H, W, n_bins, w.keys, w.slots, w.hist);
   else
-    hipLaunchKernelGGL(k_voxel_keys<false>, kgrid, dim3(kBlock), 0, s, g, coor,
-                       gr, N, D, H, W, n_bins, w.keys, w.slots, w.hist);
+    hipLaunchKernelGGL(k_voxel_keys<0>, kgrid, dim3(kBlock), 0, s, g, cr, coor, gr, N,
+                       D, H, W, n_bins, w.keys, w.slots, w.hist);
   const int n_scan_blocks = (int)((n_bins + kScanBlock - 1) / kScanBlock);
   hipLaunchKernelGGL(k_scan_reduce, dim3(n_scan_blocks), dim3(kBlock), 0, s,
                      w.hist, n_bins, w.block_sums);
-  hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(kBlock), 0, s, w.block_sums,
-                     n_scan_blocks, counts);
   const int64_t tiles_per_batch = voxels_per_batch / kTileV;
-  hipLaunchKernelGGL(k_scan_emit, dim3(n_scan_blocks), dim3(kBlock), 0, s,
-                     w.hist, n_bins, w.block_sums, w.bin_start, interval_starts,
-                     interval_lengths, reinterpret_cast<int4*>(plan),
-                     voxels_per_batch, tiles_per_batch);
-  hipLaunchKernelGGL(k_scatter, dim3(pb), dim3(kBlock), 0, s, w.keys, w.slots,
-                     P, w.bin_start, w.tmp_point);
+  hipLaunchKernelGGL(k_scan_emit, dim3(n_scan_blocks), dim3(kBlock), 0, s, w.hist,
+                     n_bins, w.block_sums, table, interval_starts, interval_lengths,
+                     reinterpret_cast<int4*>(plan), voxels_per_batch, tiles_per_batch,
+                     counts);
+  hipLaunchKernelGGL(k_scatter, dim3(pb), dim3(kBlock), 0, s, w.keys, w.slots, P,
+                     table, w.tmp_point);
   hipLaunchKernelGGL(k_rank_in_bin, dim3(pb), dim3(kBlock), 0, s, w.keys,
-                     w.tmp_point, counts, w.bin_start, w.hist, D, H * W,
-                     ranks_bev, ranks_depth, ranks_feat);
+                     w.tmp_point, counts, table, D, H * W, ranks_bev, ranks_depth,
+                     ranks_feat);
   return launch_status();
+}
+
+int veon_lss_prepare(int B, int N, int D, int H, int W, const float* coor,
+                     const float* xs, const float* ys, const float* ds,
+                     const float* post_rots_inv, const float* post_trans,
+                     const float* combine, const float* trans, const float* bda,
+                     const float* grid_lower, const float* grid_interval,
+                     const float* grid_size, int64_t voxels_per_batch,
+                     void* workspace, int64_t workspace_bytes, int* ranks_bev,
+                     int* ranks_depth, int* ranks_feat, int* interval_starts,
+                     int* interval_lengths, int* plan, int* counts,
+                     void* stream) {
+  return prepare_impl(B, N, D, H, W, coor, xs, ys, ds, post_rots_inv, post_trans,
+                      combine, trans, bda, nullptr, nullptr, nullptr, grid_lower,
+                      grid_interval, grid_size, voxels_per_batch, workspace,
+                      workspace_bytes, 0, ranks_bev, ranks_depth, ranks_feat,
+                      interval_starts, interval_lengths, plan, nullptr, counts, stream);
+}
+
+int veon_lss_prepare_cameras(int B, int N, int D, int H, int W, const float* xs,
+                             const float* ys, const float* ds,
+                             const float* sensor2ego, const float* cam2imgs,
+                             const float* post_rots, const float* post_trans,
+                             const float* bda, const float* grid_lower,
+                             const float* grid_interval, const float* grid_size,
+                             int64_t voxels_per_batch, void* workspace,
+                             int64_t workspace_bytes, int hist_is_zero,
+                             int* ranks_bev, int* ranks_depth, int* ranks_feat,
+                             int* interval_starts, int* interval_lengths, int* plan,
+                             int* vstart, int* counts, void* stream) {
+  if (!sensor2ego) return VEON_ERR_BAD_ARG;
+  return prepare_impl(B, N, D, H, W, nullptr, xs, ys, ds, nullptr, post_trans, nullptr,
+                      nullptr, bda, sensor2ego, cam2imgs, post_rots, grid_lower,
+                      grid_interval, grid_size, voxels_per_batch, workspace,
+                      workspace_bytes, hist_is_zero, ranks_bev, ranks_depth,
+                      ranks_feat, interval_starts, interval_lengths, plan, vstart,
+                      counts, stream);
 }
 
 }  // extern "C"

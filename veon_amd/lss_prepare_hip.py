@@ -67,9 +67,55 @@ def camera_matrices(sensor2ego, cam2imgs, post_rots):
 
 
 class Prepared:
-    """Full-capacity device buffers of one prepare call (no host sync yet)."""
+    """Full-capacity device buffers of one prepare call (no host sync yet).
+    ``vstart``: the dense voxel table of the row pool kernels (None when the call
+    did not produce it)."""
     __slots__ = ('ranks_bev', 'ranks_depth', 'ranks_feat', 'interval_starts',
-                 'interval_lengths', 'plan', 'counts', 'batch', 'vpb')
+                 'interval_lengths', 'plan', 'counts', 'batch', 'vpb', 'vstart')
+
+
+class LiftWorkspace(Prepared):
+    """Every device buffer of the per-call, sync-free lift for one problem size,
+    allocated ONCE (and the histogram zeroed once): a steady-state call allocates
+    nothing, so a hipGraph capture of it owns no memory, and it needs no memset
+    node.  The buffers are overwritten by the next call on the same stream."""
+    __slots__ = ('ws', 'ws_bytes', 'dims')
+
+    def __init__(self, dims, vpb, device):
+        B, N, D, H, W = dims
+        L = _lib.lib()
+        P = B * N * D * H * W
+        self.dims, self.batch, self.vpb = tuple(dims), B, vpb
+        self.ws_bytes = L.veon_lss_prepare_workspace_bytes(P, vpb * B)
+        self.ws = torch.zeros(self.ws_bytes, dtype=torch.uint8, device=device)
+        i32 = dict(dtype=torch.int32, device=device)
+        self.ranks_bev = torch.empty(P, **i32)
+        self.ranks_depth = torch.empty(P, **i32)
+        self.ranks_feat = torch.empty(P, **i32)
+        self.interval_starts = torch.empty(P, **i32)
+        self.interval_lengths = torch.empty(P, **i32)
+        self.counts = torch.zeros(2, **i32)
+        self.vstart = torch.zeros(L.veon_bev_pool_voxel_table_ints(B, vpb), **i32)
+        self.plan = None
+        if vpb % 64 == 0:
+            self.plan = torch.zeros(L.veon_bev_pool_plan_ints(B, vpb), **i32)
+
+
+_WORKSPACES = {}
+
+
+def lift_workspace(dims, vpb, device):
+    """The LiftWorkspace of (problem size, device, current stream): two streams
+    lifting at once never share buffers."""
+    key = (tuple(dims), int(vpb), str(device),
+           int(torch._C._cuda_getCurrentRawStream(
+               device.index if device.index is not None else torch.cuda.current_device())))
+    ws = _WORKSPACES.get(key)
+    if ws is None:
+        with torch.cuda.device(device):
+            ws = LiftWorkspace(dims, int(vpb), device)
+        _WORKSPACES[key] = ws
+    return ws
 
 
 def _grid_host(lower, interval, gsize):
@@ -93,6 +139,7 @@ def prepare_device(dims, coor, geometry, lower, interval, gsize, device):
     ws_bytes = L.veon_lss_prepare_workspace_bytes(P, vpb * B)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
     out = Prepared()
+    out.vstart = None
     out.batch, out.vpb = B, vpb
     out.ranks_bev = torch.empty(P, dtype=torch.int32, device=device)
     out.ranks_depth = torch.empty(P, dtype=torch.int32, device=device)
@@ -129,6 +176,35 @@ def prepare_device(dims, coor, geometry, lower, interval, gsize, device):
     _lib.check(st, 'veon_lss_prepare')
     del keep
     return out
+
+
+def prepare_cameras(frustum, sensor2ego, cam2imgs, post_rots, post_trans, bda, lower,
+                    interval, gsize):
+    """The sync-free per-call prepare from the reference's camera tensors
+    (get_lidar_coor's arguments) into the static LiftWorkspace: five launches, no
+    allocation, no memset, no host sync.  Returns the workspace (a ``Prepared``
+    with ``vstart``)."""
+    dev = _lib.require_device(sensor2ego, cam2imgs, post_rots, post_trans, bda)
+    B, N = sensor2ego.shape[:2]
+    D, H, W, _ = frustum.shape
+    vpb = _vpb(gsize)
+    ws = lift_workspace((B, N, D, H, W), vpb, dev)
+    xs, ys, ds = _axes(frustum, dev)
+    s2e, k, pr, pt, bd = (_f32c(t) for t in (sensor2ego, cam2imgs, post_rots, post_trans,
+                                              bda))
+    glo, gstep, gsz = _grid_host(lower, interval, gsize)
+    with _lib.on_device(dev):
+        st = _lib.lib().veon_lss_prepare_cameras(
+            B, N, D, H, W, _lib.ptr(xs), _lib.ptr(ys), _lib.ptr(ds), _lib.ptr(s2e),
+            _lib.ptr(k), _lib.ptr(pr), _lib.ptr(pt), _lib.ptr(bd),
+            ctypes.cast(glo, ctypes.c_void_p), ctypes.cast(gstep, ctypes.c_void_p),
+            ctypes.cast(gsz, ctypes.c_void_p), vpb, _lib.ptr(ws.ws), ws.ws_bytes, 1,
+            _lib.ptr(ws.ranks_bev), _lib.ptr(ws.ranks_depth), _lib.ptr(ws.ranks_feat),
+            _lib.ptr(ws.interval_starts), _lib.ptr(ws.interval_lengths),
+            _lib.ptr(ws.plan), _lib.ptr(ws.vstart), _lib.ptr(ws.counts),
+            _lib.stream_ptr(dev))
+    _lib.check(st, 'veon_lss_prepare_cameras')
+    return ws
 
 
 def _finish(pre):

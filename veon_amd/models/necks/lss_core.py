@@ -161,12 +161,9 @@ class LSSCore(_Base):
 
     def _lift_sync_free(self, input, depth, feat):
         sensor2ego, _, cam2imgs, post_rots, post_trans, bda = input[1:7]
-        pri, comb, trans = _prep._HIP_PREPARE.camera_matrices(
-            sensor2ego, cam2imgs, post_rots)
-        pre = _prep._HIP_PREPARE.prepare_from_matrices(
-            self.frustum, pri, post_trans, comb, trans, bda,
-            self.grid_lower_bound, self.grid_interval, self.grid_size,
-            sync=False)
+        pre = _prep._HIP_PREPARE.prepare_cameras(
+            self.frustum, sensor2ego, cam2imgs, post_rots, post_trans, bda,
+            self.grid_lower_bound, self.grid_interval, self.grid_size)
         shape = self._bev_feat_shape(depth.shape[0], feat.shape[2])
         feat_l = feat.permute(0, 1, 3, 4, 2)
         out = None
@@ -195,16 +192,13 @@ class LSSCore(_Base):
                 out_volume=out_volume)
         sensor2ego, _, cam2imgs, post_rots, post_trans, bda = input[1:7]
         if self.sync_free:
-            pri, comb, trans = _prep._HIP_PREPARE.camera_matrices(
-                sensor2ego, cam2imgs, post_rots)
-            pre = _prep._HIP_PREPARE.prepare_from_matrices(
-                self.frustum, pri, post_trans, comb, trans, bda,
-                self.grid_lower_bound, self.grid_interval, self.grid_size,
-                sync=False)
+            pre = _prep._HIP_PREPARE.prepare_cameras(
+                self.frustum, sensor2ego, cam2imgs, post_rots, post_trans, bda,
+                self.grid_lower_bound, self.grid_interval, self.grid_size)
             return _bp.bev_pool_v2_maxpool(
                 depth, feat, pre.ranks_depth, pre.ranks_feat, pre.ranks_bev,
                 shape, pre.interval_starts, pre.interval_lengths, ds,
-                counts=pre.counts, out_volume=out_volume)
+                counts=pre.counts, out_volume=out_volume, vstart=pre.vstart)
         pri, comb, trans = _prep.camera_matrices(sensor2ego, cam2imgs, post_rots)
         ranks = _prep.prepare_from_matrices(
             self.frustum, pri, post_trans, comb, trans, bda,

@@ -208,26 +208,16 @@ def _voxel_table(ranks_bev, interval_starts, batch, vpb):
     return vstart
 
 
-# Row kernels (csrc/bev_pool_rows.hip) take over from the slab kernels at this
-# channel count: one feature row is then >= 512 bytes and a workgroup reads it
-# once, full width (measured on MI355X: tools/kbench.py).
+# Row kernels (csrc/bev_pool_rows.hip) take over from the slab kernels at these
+# channel counts (measured on MI355X, tools/poolbench.py: at C = 80 the fused
+# max-pool is 34 -> 30 us with them, the full-resolution volume 34-40 -> 53 us;
+# at C = 256 they win 2.3x / 3x).
 ROWS_MIN_C = 128
-
-
-# the row kernels' optional depth pre-sort (one dependent load level less per wave)
-ROWS_SORT_DEPTH = True
-
-
-def _dsort_ws(ranks_depth, sort_depth):
-    if sort_depth is None:
-        sort_depth = ROWS_SORT_DEPTH
-    if not sort_depth or ranks_depth.numel() == 0:
-        return None
-    return torch.empty(ranks_depth.numel(), dtype=torch.float32, device=ranks_depth.device)
+ROWS_MIN_C_MAXPOOL = 64
 
 
 def rows_forward(depth, feat, ranks_depth, ranks_feat, vstart, bev_feat_shape,
-                 out=None, variant=0, sort_depth=None):
+                 out=None, variant=0):
     """(B,C,Z,Y,X) fp32 volume by the row kernel, from the dense voxel table."""
     B, Z, Y, X, C = [int(s) for s in bev_feat_shape]
     dev = _lib.require_device(depth, feat, ranks_depth, ranks_feat, vstart)
@@ -238,18 +228,17 @@ def rows_forward(depth, feat, ranks_depth, ranks_feat, vstart, bev_feat_shape,
     elif (tuple(out.shape) != (B, C, Z, Y, X) or out.dtype != torch.float32
           or not out.is_contiguous() or out.device != dev):
         raise _lib.VeonHipError('out must be a contiguous fp32 (B,C,Z,Y,X) tensor')
-    ws = _dsort_ws(ranks_depth, sort_depth)
     with _lib.on_device(dev):
         st = _lib.lib().veon_bev_pool_v2_fwd_rows(
             C, B, Z * Y * X, _lib.ptr(depth), _lib.ptr(feat), _feat_code(feat),
             _lib.ptr(ranks_depth), _lib.ptr(ranks_feat), _lib.ptr(vstart),
-            _lib.ptr(ws), _lib.ptr(out), 0, variant, _lib.stream_ptr(dev))
+            _lib.ptr(out), 0, feat.numel(), variant, _lib.stream_ptr(dev))
     _lib.check(st, 'veon_bev_pool_v2_fwd_rows')
     return out
 
 
 def rows_maxpool(depth, feat, ranks_depth, ranks_feat, vstart, bev_feat_shape, ds,
-                 out_volume=None, sort_depth=None):
+                 out_volume=None):
     """Pool + (2,2,2) block max by the row kernel: (B,C,Z/2,Y/2,X/2) fp32, or the
     Conv3d body's padded bf16 input when ``out_volume`` is given."""
     B, Z, Y, X, C = [int(s) for s in bev_feat_shape]
@@ -266,18 +255,20 @@ def rows_maxpool(depth, feat, ranks_depth, ranks_feat, vstart, bev_feat_shape, d
         ret = torch.empty((B, C, Z // dz, Y // dy, X // dx), dtype=torch.float32,
                           device=dev)
         target, padded = ret, 0
-    ws = _dsort_ws(ranks_depth, sort_depth)
     with _lib.on_device(dev):
         st = _lib.lib().veon_bev_pool_v2_fwd_rows_maxpool(
             C, B, Z, Y, X, dz, dy, dx, _lib.ptr(depth), _lib.ptr(feat),
             _feat_code(feat), _lib.ptr(ranks_depth), _lib.ptr(ranks_feat),
-            _lib.ptr(vstart), _lib.ptr(ws), _lib.ptr(target), padded, _lib.stream_ptr(dev))
+            _lib.ptr(vstart), _lib.ptr(target), padded, feat.numel(),
+            _lib.stream_ptr(dev))
     _lib.check(st, 'veon_bev_pool_v2_fwd_rows_maxpool')
     return ret
 
 
-def _rows_ok(C, ds=None):
-    if C < ROWS_MIN_C or C % 4:
+def _rows_ok(C, ds=None, feat=None):
+    if C < (ROWS_MIN_C if ds is None else ROWS_MIN_C_MAXPOOL) or C % 4:
+        return False
+    if feat is not None and feat.numel() >= 2 ** 31:   # 32-bit row offsets inside
         return False
     return ds is None or tuple(int(v) for v in ds) == (2, 2, 2)
 
@@ -298,7 +289,7 @@ def _fused_forward(depth, feat, ranks_depth, ranks_feat, ranks_bev,
         out = torch.empty((B, C, Z, Y, X), dtype=torch.float32, device=dev)
     else:
         out = torch.empty((B, Z, Y, X, C), dtype=torch.float32, device=dev)
-    if layout == _lib.LAYOUT_BCZYX and _rows_ok(C):
+    if layout == _lib.LAYOUT_BCZYX and _rows_ok(C, feat=feat):
         vstart = _voxel_table(ranks_bev, interval_starts, B, Z * Y * X)
         return rows_forward(depth, feat, ranks_depth, ranks_feat, vstart,
                             bev_feat_shape, out=out)
@@ -438,15 +429,18 @@ def bev_pool_v2_prepared(depth, feat, pre, bev_feat_shape, out=None):
     B, Z, Y, X, C = [int(s) for s in bev_feat_shape]
     if pre.batch != B or pre.vpb != Z * Y * X:
         raise _lib.VeonHipError('prepared ranks do not match bev_feat_shape')
+    dev = _lib.require_device(depth, feat, pre.ranks_bev)
+    if out is not None and (tuple(out.shape) != (B, C, Z, Y, X) or out.dtype != torch.float32
+                            or not out.is_contiguous() or out.device != dev):
+        raise _lib.VeonHipError('out must be a contiguous fp32 (B,C,Z,Y,X) tensor')
+    if getattr(pre, 'vstart', None) is not None and _rows_ok(C, feat=feat):
+        return rows_forward(depth, feat, pre.ranks_depth, pre.ranks_feat, pre.vstart,
+                            bev_feat_shape, out=out)
     if pre.plan is None:  # voxel count not a multiple of the tile: build it now
         pre.plan = build_plan(pre.ranks_bev, pre.interval_starts, B, Z * Y * X,
                               attach=False, counts=pre.counts)
-    dev = _lib.require_device(depth, feat, pre.ranks_bev)
     if out is None:
         out = torch.empty((B, C, Z, Y, X), dtype=torch.float32, device=dev)
-    elif (tuple(out.shape) != (B, C, Z, Y, X) or out.dtype != torch.float32
-          or not out.is_contiguous() or out.device != dev):
-        raise _lib.VeonHipError('out must be a contiguous fp32 (B,C,Z,Y,X) tensor')
     with _lib.on_device(dev):
         st = _lib.lib().veon_bev_pool_v2_fwd_fused_ex(
             C, pre.interval_starts.numel(), B, Z * Y * X, _lib.ptr(depth),
@@ -481,7 +475,7 @@ def build_row_table(ranks_bev, interval_starts, batch, voxels_per_batch,
 
 def bev_pool_v2_maxpool(depth, feat, ranks_depth, ranks_feat, ranks_bev,
                         bev_feat_shape, interval_starts, interval_lengths, ds,
-                        counts=None, out_volume=None):
+                        counts=None, out_volume=None, vstart=None):
     """Inference-only fusion of ``bev_pool_v2`` with the (dz,dy,dx) block max of
     LSSViewTransformerRaw.forward (view_transformer_raw.py:545-553): returns
     (B, C, Z/dz, Y/dy, X/dx) without writing the full-resolution volume.
@@ -489,15 +483,17 @@ def bev_pool_v2_maxpool(depth, feat, ranks_depth, ranks_feat, ranks_bev,
     ascending in voxel rank (what the prepare produces).  ``out_volume`` (a
     ``conv3d_ops.PaddedVolume`` of shape (B,C,Z/dz,Y/dy,X/dx)) receives the
     result rounded to bf16 in the Conv3d body's input layout instead, and is
-    returned."""
+    returned.  ``counts`` / ``vstart``: device-side sizes and dense voxel table of
+    a sync-free prepare (capacity-sized rank buffers)."""
     depth = depth.contiguous().float()
     feat = _inference_feat(feat, depth)
     B, Z, Y, X, C = [int(s) for s in bev_feat_shape]
     dz, dy, dx = [int(v) for v in ds]
     dev = _lib.require_device(depth, feat, ranks_depth, ranks_feat, ranks_bev,
                               interval_starts, interval_lengths)
-    if counts is None and _rows_ok(C, ds):
-        vstart = _voxel_table(ranks_bev, interval_starts, B, Z * Y * X)
+    if _rows_ok(C, ds, feat) and (counts is None or vstart is not None):
+        if vstart is None:
+            vstart = _voxel_table(ranks_bev, interval_starts, B, Z * Y * X)
         return rows_maxpool(depth, feat, ranks_depth, ranks_feat, vstart,
                             bev_feat_shape, ds, out_volume=out_volume)
     table = None
