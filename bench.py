@@ -7,19 +7,36 @@ A "step" is one pass of the hot path over one synthetic 6-camera sample:
 ``view_transformer.view_transform(input, depth, tran_feat)`` -- the region the
 reference's own benchmark times (tools/analysis_tools/benchmark_view_transformer.py:
 120-138), with pre-computed ranks (``accelerate=True``, that tool's default).
-Workload = BASELINE.json configs[1]: 6 cams, 256x704, D=59, C=80, 200x200x16
+Workload = BASELINE.json configs[1] (S2): 6 cams, 256x704, D=59, C=80, 200x200x16
 voxels.  Inputs are resident in HBM before the timed region.  N>1: one process
 per GPU (torchrun), independent samples per rank, no data-path collective
 ("weak" scaling); the wall time is the max over ranks.
 
-Rank 0 prints ONE JSON line with `roofline` (bev_pool_v2 fused kernel, HBM
-bound, algorithmic bytes / mean launch time from HIP events) and `cpu_baseline`
-(the pure-PyTorch index_add_ port of the same step on the host cores).
+Rank 0 prints ONE JSON line.  `roofline` is the dominant kernel of the step
+(k_pool_fused_cf, HBM bound): algorithmic bytes / mean launch time from HIP
+events on the launch stream, into whatever buffer the allocator hands out (no
+placement search: `--placement` adds the tuned-placement figure as a secondary
+key).  `roofline.traffic` comes from two rocprofv3 --pmc passes run as child
+processes of this script (FETCH_SIZE, WRITE_SIZE; N=1 only).  At N=1 the line
+also carries
+  `sv`    the VEON-shaped lift (6 cams 512x1408, D=88, C=256): the fused forward
+          (691.7 MB algorithmic) and the fused pool + 2x2x2 max-pool (118 MB fp32 /
+          the Conv3d body's bf16 input), each with its own roofline numbers;
+  `veonb` BASELINE configs[2]: the whole 3-D occupancy path (DA-V2 ViT-B + CLIP
+          ViT-B/16 + HSA + lift + Conv3d body + heads), ms per 6-camera sample and
+          the MFMA roofline of its conv body;
+  `cpu_baseline` the pure-PyTorch index_add_ port of the step on the host cores,
+          at the best of several thread counts.
 """
 import argparse
+import csv
+import glob
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 import torch
@@ -28,7 +45,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
-
 MFMA_PEAK_TFLOPS = 2500.0  # dense bf16, same guide
 
 WORKLOADS = {
@@ -42,106 +58,215 @@ WORKLOADS = {
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument('--gpus', type=int, default=1)
-    p.add_argument('--steps', type=int, default=200)
-    p.add_argument('--warmup', type=int, default=20)
-    p.add_argument('--workload', default='S2', choices=sorted(WORKLOADS) + ['VEONB'],
-                   help='S2 (default, BASELINE configs[1]) / SV / S1: the lift; VEONB: the '
-                        'chained hot path of BASELINE configs[2] (tools/hotpath_bench.py)')
+    p.add_argument('--steps', type=int, default=2000)
+    p.add_argument('--warmup', type=int, default=50)
+    p.add_argument('--workload', default='S2', choices=sorted(WORKLOADS) + ['VEONB', 'VEONL'],
+                   help='S2 (default, BASELINE configs[1]) / SV / S1: the lift; VEONB / '
+                        'VEONL: the chained occupancy path of BASELINE configs[2] / [3]')
     p.add_argument('--no-graph', action='store_true',
                    help='eager launches instead of a captured hipGraph')
     p.add_argument('--shard', default='replicas', choices=['replicas', 'cameras'],
                    help='replicas: one sample per GPU, no collective (default); '
                         'cameras: the six cameras of ONE sample split over the '
                         'GPUs + RCCL all-reduce of the voxel volume')
-    p.add_argument('--no-placement', action='store_true',
-                   help='do not keep / tune a persistent output volume '
-                        '(veon_amd/placement.py); the allocator places it')
+    p.add_argument('--placement', action='store_true',
+                   help='also report the kernel into a placement-tuned persistent '
+                        'output volume (veon_amd/placement.py) as roofline.placed')
     p.add_argument('--no-cpu-baseline', action='store_true')
-    p.add_argument('--cpu-seconds', type=float, default=12.0)
-    p.add_argument('--pmc-traffic', type=float, default=None,
-                   help='HBM bytes per launch from a separate rocprofv3 --pmc '
-                        'run (profiles/), copied into roofline.traffic')
+    p.add_argument('--cpu-seconds', type=float, default=10.0)
+    p.add_argument('--no-sv', action='store_true', help='skip the `sv` sub-object')
+    p.add_argument('--no-veonb', action='store_true', help='skip the `veonb` sub-object')
+    p.add_argument('--no-pmc', action='store_true',
+                   help='skip the rocprofv3 --pmc child passes (roofline.traffic = null)')
     return p.parse_args()
 
 
-def committed_pmc_traffic(workload):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes
-    (profiles/r01_pmc_hbm_bytes.json: two separate `rocprofv3 --pmc` runs of this
-    script, FETCH_SIZE and WRITE_SIZE in KiB).  WRITE_SIZE is exact for these
-    stores; FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950
-    (an upper bound here: the guide calibrates the x2 for wide streaming reads,
-    these are gathers).  None when the file or the kernel is missing."""
-    if workload != 'S2':
-        return None, None
-    path = os.path.join(ROOT, 'profiles', 'r01_pmc_hbm_bytes.json')
-    try:
-        with open(path) as f:
-            data = json.load(f)
-        for name, c in data.items():
-            if 'k_pool_fused_cf<4, 32' in name:
-                b = (c['WRITE_SIZE']['mean_KiB'] + 2.0 * c['FETCH_SIZE']['mean_KiB']) * 1024.0
-                return round(b), 'profiles/r01_pmc_hbm_bytes.json (WRITE_SIZE + 2 x FETCH_SIZE)'
-    except (OSError, KeyError, ValueError):
-        pass
-    return None, None
-
-
-def algorithmic_bytes(n_cams, hf, wf, C, D, p_kept, n_intervals, n_vox, batch=1):
+def algorithmic_bytes(n_cams, hf, wf, C, D, p_kept, n_intervals, n_vox, batch=1,
+                      feat_bytes=4, out_bytes=4, out_div=1):
     """feat once + depth once + 3 rank arrays + 2 interval arrays
-    + the output volume written once (zeros included), fp32/int32."""
-    return 4 * (batch * n_cams * hf * wf * C + batch * n_cams * D * hf * wf +
-                3 * p_kept + 2 * n_intervals + batch * n_vox * C)
+    + the output volume written once (zeros included)."""
+    return (batch * n_cams * hf * wf * C * feat_bytes + 4 * batch * n_cams * D * hf * wf +
+            4 * (3 * p_kept + 2 * n_intervals) + batch * n_vox * C * out_bytes // out_div)
+
+
+def event_ms(fn, iters, warm=5):
+    """Mean time of `fn` over `iters` back-to-back calls, HIP events on the stream
+    the kernels are launched on (torch's current stream)."""
+    for _ in range(warm):
+        fn()
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def timed_steps(run, steps, warmup, dist, dev, rehearse=False):
+    """W warm-up steps, then exactly K steps between barrier + synchronize on both
+    sides; max over ranks."""
+    for _ in range(warmup):
+        run()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        run()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64,
+                         device='cpu' if (rehearse or dist.get_backend() == 'gloo') else dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed
+
+
+# ---------------------------------------------------------------------------
+# PMC traffic: rocprofv3 child processes (counters cannot be read in-process)
+# ---------------------------------------------------------------------------
+def pmc_traffic():
+    """{kernel-name substring: (FETCH_SIZE KiB, WRITE_SIZE KiB) mean per launch}
+    from two separate `rocprofv3 --pmc` passes of tools/pool_case.py ALL, run as
+    children of this process; {} when rocprofv3 is unavailable or fails."""
+    exe = shutil.which('rocprofv3')
+    if exe is None:
+        return {}, 'rocprofv3 not on PATH'
+    out = {}
+    tmp = tempfile.mkdtemp(prefix='veon_pmc_', dir='/tmp')
+    env = dict(os.environ, TMPDIR='/tmp')
+    try:
+        for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+            d = os.path.join(tmp, counter)
+            cmd = [exe, '--pmc', counter, '--output-format', 'csv', '-d', d, '--',
+                   sys.executable, os.path.join(ROOT, 'tools', 'pool_case.py'), 'ALL']
+            r = subprocess.run(cmd, cwd='/tmp', env=env, stdout=subprocess.PIPE,
+                               stderr=subprocess.STDOUT, timeout=240)
+            if r.returncode != 0:
+                return {}, 'rocprofv3 --pmc %s exited %d' % (counter, r.returncode)
+            vals = {}
+            for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'),
+                               recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if row['Counter_Name'] == counter:
+                        vals.setdefault(row['Kernel_Name'], []).append(
+                            float(row['Counter_Value']))
+            for k, v in vals.items():
+                out.setdefault(k, {})[counter] = sum(v) / len(v)
+    except (subprocess.TimeoutExpired, OSError) as e:
+        return {}, 'rocprofv3 child failed: %r' % (e,)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return out, 'two rocprofv3 --pmc child passes of tools/pool_case.py in this run'
+
+
+def traffic_of(pmc, needle):
+    """WRITE_SIZE + 2 x FETCH_SIZE in bytes for the first kernel whose name
+    contains `needle` (MI355X_MICROARCH.md: FETCH_SIZE under-reports wide reads by
+    2x on gfx950, WRITE_SIZE is exact; for gathers the x2 is an upper bound)."""
+    for k, c in pmc.items():
+        if needle in k and 'FETCH_SIZE' in c and 'WRITE_SIZE' in c:
+            return int((c['WRITE_SIZE'] + 2.0 * c['FETCH_SIZE']) * 1024.0)
+    return None
+
+
+# ---------------------------------------------------------------------------
+# sub-objects
+# ---------------------------------------------------------------------------
+def sv_subobject(dev, pmc):
+    """The VEON-shaped lift (SV): fused forward and fused pool + max-pool kernels,
+    each with its own algorithmic bytes (never mixed)."""
+    from tools._inputs import lift_case
+    from veon_amd import conv3d_ops, synthetic
+    from veon_amd.ops.bev_pool_v2 import bev_pool as bp
+    grid, size, cams, C = synthetic.GRID_VEON, (512, 1408), 6, 256
+    cs = lift_case(grid, size, cams, C, str(dev))
+    depth, feat = cs['depth'], cs['feat_nhwc']
+    rb, rd, rf, st = cs['rb'], cs['rd'], cs['rf'], cs['st']
+    X, Y, Z = cs['gsize']
+    D, hf, wf = cs['D'], size[0] // 16, size[1] // 16
+    vpb = Z * Y * X
+    shape = (1, Z, Y, X, C)
+    vs = bp.build_voxel_table(rb, st, 1, vpb, attach=False)
+    fb = feat.bfloat16()
+    out = torch.empty((1, C, Z, Y, X), dtype=torch.float32, device=dev)
+    vol = conv3d_ops.PaddedVolume(1, C, Z // 2, Y // 2, X // 2, dev)
+    p, i = rb.numel(), st.numel()
+    cases = {
+        'fused': ('k_rows_fused_cf', 'bev_pool_v2 -> (B,C,Z,Y,X) fp32',
+                  algorithmic_bytes(cams, hf, wf, C, D, p, i, vpb),
+                  lambda: bp.rows_forward(depth, feat, rd, rf, vs, shape, out=out)),
+        'maxpool': ('k_rows_maxpool<0', 'bev_pool_v2 + 2x2x2 max-pool -> (B,C,Z/2,Y/2,X/2) fp32',
+                    algorithmic_bytes(cams, hf, wf, C, D, p, i, vpb, out_div=8),
+                    lambda: bp.rows_maxpool(depth, feat, rd, rf, vs, shape, (2, 2, 2))),
+        'maxpool_bf16': ('k_rows_maxpool<2', 'the same from bf16 rows into the Conv3d body\'s '
+                         'padded bf16 input (what the VEON path runs)',
+                         algorithmic_bytes(cams, hf, wf, C, D, p, i, vpb, feat_bytes=2,
+                                           out_bytes=2, out_div=8),
+                         lambda: bp.rows_maxpool(depth, fb, rd, rf, vs, shape, (2, 2, 2),
+                                                 out_volume=vol)),
+    }
+    res = {'workload': 'SV: 6-cam 512x1408, D=%d, C=%d, %dx%dx%d voxels (configs/veon), '
+                       'cached ranks' % (D, C, X, Y, Z),
+           'points_kept': p, 'intervals': i}
+    for key, (kname, what, alg, fn) in cases.items():
+        ms = event_ms(fn, 50)
+        gbs = alg / (ms * 1e-3) / 1e9
+        res[key] = {'kernel': kname.split('<')[0], 'what': what, 'bound': 'hbm',
+                    'algorithmic_bytes': alg, 'kernel_ms': round(ms, 5),
+                    'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                    'frac': round(gbs / HBM_PEAK_GBS, 4),
+                    'traffic': traffic_of(pmc, kname)}
+    return res
+
+
+def veon_path(args, dev, encoder, size, steps, warmup, dist, world):
+    """One chained occupancy-path workload -> (ms per step, stage dict, body TFLOP/s)."""
+    from tools import hotpath_bench
+    r = hotpath_bench.run_full(encoder, size, dev=str(dev), iters=5, verbose=False)
+    step = r['step']
+    with torch.no_grad():
+        el = timed_steps(step, steps, warmup, dist, dev)
+    ms = el / steps * 1e3
+    body_flops = 8 * 2.0 * 8 * 100 * 100 * 256 * 256 * 27
+    tf = body_flops / (r['body_ms'] * 1e-3) / 1e12
+    stages = {k: round(v, 3) for k, v in r.items() if k.endswith('_ms')}
+    return ms, stages, tf
+
+
+VEON_WHAT = ('the 3-D occupancy path of VeonTemporal.simple_test '
+             '(veon_amd/models/veon_occ.py): DA-V2 %s + DPT head -> depth; CLIP %s first '
+             'blocks -> HSA network -> CLIP tail with attention biases; CatFusionLift -> '
+             'sync-free lift (D=88, C=256, 200x200x16, fused 2x2x2 max-pool) -> 4x '
+             'ResBlock3D -> occ/sem heads -> open-vocab classifier -> upsample -> arg-max; '
+             'bf16 on MFMA, random weights; timm side-adapter ViT / mask decoder / text '
+             'encoder not included')
 
 
 def bench_hotpath(args, rank, world, dev, dist):
-    """BASELINE configs[2] shape: DA-V2 ViT-B + CLIP ViT-B/16 + lift + Conv3d body
-    + heads, bf16, one 6-camera 256x704 sample per step (replicas for N > 1).
-    The roofline object is the dominant MFMA kernel (the 3x3x3 conv body)."""
-    from tools import hotpath_bench
-    r = hotpath_bench.run_full('vitb', (256, 704), dev=str(dev), iters=5, verbose=False)
-    step = r['step']
-    with torch.no_grad():
-        for _ in range(args.warmup):
-            step()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        el = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([el], dtype=torch.float64,
-                         device='cpu' if dist.get_backend() == 'gloo' else dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
+    """--workload VEONB / VEONL: the whole path as the timed step (replicas for N > 1)."""
+    enc = 'vitb' if args.workload == 'VEONB' else 'vitl'
+    ms, stages, tf = veon_path(args, dev, enc, (256, 704), args.steps, args.warmup, dist, world)
     if rank != 0:
         return
-    ms = el / args.steps * 1e3
-    body_flops = 8 * 2.0 * 8 * 100 * 100 * 256 * 256 * 27
-    tf = body_flops / (r['body_ms'] * 1e-3) / 1e12
     print(json.dumps({
         'metric': '6cam_hotpath_samples_per_sec', 'value': round(world * 1e3 / ms, 2),
         'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(ms, 4), 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
-        'config': {'workload': 'VEONB: the 3-D occupancy path of VeonTemporal.simple_test '
-                               '(veon_amd/models/veon_occ.py), 6-cam 256x704: DA-V2 ViT-B + DPT '
-                               'head -> depth; CLIP ViT-B/16 first 9 blocks -> HSA network -> '
-                               'CLIP tail with attention biases; CatFusionLift -> sync-free lift '
-                               '(D=88, C=256, 200x200x16, fused 2x2x2 max-pool) -> 4x ResBlock3D '
-                               '-> occ/sem heads -> open-vocab classifier -> upsample -> arg-max; '
-                               'bf16 on MFMA, random weights; timm side-adapter ViT / mask '
-                               'decoder / text encoder not included',
-                   'parallelism': 'replicas x%d' % world,
-                   'stages_ms': {k: round(v, 3) for k, v in r.items() if k.endswith('_ms')}},
+        'config': {'workload': '%s, 6-cam 256x704: ' % args.workload +
+                               VEON_WHAT % ('ViT-B' if enc == 'vitb' else 'ViT-L', 'ViT-B/16'),
+                   'parallelism': 'replicas x%d' % world, 'stages_ms': stages},
         'roofline': {'kernel': 'k_conv3d_k3 (8 launches, AlignNetOcc3D body)', 'bound': 'mfma',
                      'achieved': round(tf, 1), 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                      'frac': round(tf / MFMA_PEAK_TFLOPS, 4), 'traffic': None},
-        'cpu_baseline': None}))
+        'cpu_baseline': None}), flush=True)
 
 
 def main():
@@ -173,8 +298,11 @@ def main():
     from veon_amd.ops.bev_pool_v2 import bev_pool as bp
     _lib.lib()  # fail loudly if the HIP library is missing
 
-    if args.workload == 'VEONB':
-        return bench_hotpath(args, rank, world, dev, dist)
+    if args.workload in ('VEONB', 'VEONL'):
+        bench_hotpath(args, rank, world, dev, dist)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
 
     grid_key, input_size, n_cams, C, neck_type = WORKLOADS[args.workload]
     grid = getattr(synthetic, grid_key)
@@ -185,9 +313,6 @@ def main():
     else:
         cfg['ds_feat'] = [1, 1, 1]
     vt = build_neck(cfg).to(dev).eval()
-    # one output volume kept across steps (a graph replay does that anyway),
-    # picked among a few allocations by timing the kernel on each
-    vt.persistent_output = not args.no_placement and args.shard == 'replicas'
     hf, wf = input_size[0] // 16, input_size[1] // 16
     D = vt.D
     rig = synthetic.make_rig(1, n_cams, input_size)
@@ -232,7 +357,7 @@ def main():
                 torch.cuda.current_stream().wait_stream(s)
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph):
-                    gout = step()
+                    step()
             except Exception as e:  # report, do not hide
                 print('hipGraph capture failed (%s); running eager' % e,
                       file=sys.stderr)
@@ -257,45 +382,30 @@ def main():
             if launch_probe['eager_us'] < launch_probe['hipGraph_us']:
                 run, graph = step, None
 
-        for _ in range(args.warmup):
-            run()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            run()
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        elapsed = time.perf_counter() - t0
-        if dist is not None:
-            tmax = torch.tensor([elapsed], dtype=torch.float64,
-                                device='cpu' if rehearse else dev)
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            elapsed = float(tmax.item())
+        elapsed = timed_steps(run, args.steps, args.warmup, dist, dev, rehearse)
 
-        # ---- kernel leg: the fused pool kernel alone, HIP events on the
-        # stream it is launched on (torch's current stream)
+        # ---- kernel leg: the fused pool kernel alone, HIP events on the stream it
+        # is launched on, into the buffer the allocator hands out (as the step)
         feat_nhwc = feat5.permute(0, 1, 3, 4, 2).contiguous()
         shape = (1, Z, Y, X, C)
+        kiters = max(args.steps, 200)
 
-        def kernel_only():
+        def kernel_only(out=None):
             return bp._fused_forward(depth5, feat_nhwc, vt.ranks_depth,
                                      vt.ranks_feat, vt.ranks_bev,
                                      vt.interval_starts, vt.interval_lengths,
-                                     shape, _lib.LAYOUT_BCZYX, out=vt._out_buf)
-        for _ in range(10):
-            kernel_only()
-        e0 = torch.cuda.Event(enable_timing=True)
-        e1 = torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize()
-        e0.record()
-        for _ in range(args.steps):
-            kernel_only()
-        e1.record()
-        torch.cuda.synchronize()
-        kernel_ms = e0.elapsed_time(e1) / args.steps
+                                     shape, _lib.LAYOUT_BCZYX, out=out)
+        kernel_ms = event_ms(kernel_only, kiters, warm=10)
+        placed = None
+        if args.placement and args.shard == 'replicas':
+            from veon_amd import placement
+            buf, info = placement.best_placed(lambda o: kernel_only(o), (1, C, Z, Y, X),
+                                              torch.float32, dev)
+            placed_ms = event_ms(lambda: kernel_only(buf), kiters, warm=10)
+            placed = {'kernel_ms': round(placed_ms, 5), 'candidates': info['candidates'],
+                      'what': 'the same launch into the fastest of several candidate '
+                              'allocations (veon_amd/placement.py); not the headline: it '
+                              'depends on what the allocator can offer on the box'}
 
         # ---- per-call leg (what every VEON config runs: accelerate=False):
         # geometry + prepare + pool each step, no host sync, hipGraph-captured
@@ -304,7 +414,6 @@ def main():
             cfg2 = dict(cfg, accelerate=False)
             vt2 = build_neck(cfg2).to(dev).eval()
             vt2.sync_free = True
-            vt2.persistent_output = vt.persistent_output
 
             def step2():
                 o = vt2.view_transform(inp, depth, tran_feat)
@@ -331,9 +440,9 @@ def main():
             el2 = time.perf_counter() - t2
             percall = {'ms_per_step': round(el2 / args.steps * 1e3, 5),
                        'samples_per_s': round(args.steps / el2, 2),
-                       'what': 'view_transform(accelerate=False, sync_free): camera '
-                               'matrices + fused geometry/counting-sort prepare + '
-                               'plan + pool per step, hipGraph'}
+                       'what': 'view_transform(accelerate=False, sync_free): geometry + '
+                               'counting-sort prepare (5 launches, static workspace) + '
+                               'pool per step, one hipGraph'}
         except Exception as e:  # report, do not hide
             print('per-call leg failed: %r' % (e,), file=sys.stderr)
 
@@ -342,9 +451,11 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = (world if args.shard == 'replicas' else 1) * args.steps / elapsed
 
-    traffic, traffic_source = args.pmc_traffic, 'command line'
-    if traffic is None:
-        traffic, traffic_source = committed_pmc_traffic(args.workload)
+    solo = rank == 0 and world == 1
+    pmc, pmc_src = ({}, 'not collected')
+    if solo and not args.no_pmc:
+        pmc, pmc_src = pmc_traffic()
+    kname = 'k_pool_fused_cf' if not bp._rows_ok(C) else 'k_rows_fused_cf'
     result = {
         'metric': '6cam_lift_samples_per_sec',
         'value': round(value, 2),
@@ -366,33 +477,52 @@ def main():
             'points_kept': p_kept, 'intervals': n_int,
             'launch': 'hipGraph' if graph is not None else 'eager',
             'launch_probe_us_per_step': launch_probe,
-            'output_volume': ('persistent, best-placed of %d allocations (kernel %.1f us vs '
-                              'median %.1f us; veon_amd/placement.py)' % (
-                                  vt.placement_info['candidates'],
-                                  vt.placement_info['best_ms'] * 1e3,
-                                  vt.placement_info['median_ms'] * 1e3)
-                              if vt.placement_info else 'allocator-placed, fresh per step'),
+            'output_volume': 'allocator-placed (torch.empty per step)',
             'parallelism': ('replicas x%d (one sample per GPU, no collective)' % world
                             if args.shard == 'replicas' else
                             'cameras sharded over %d GPUs + all-reduce of the volume' % world),
         },
         'roofline': {
-            'kernel': 'k_pool_fused_cf (bev_pool_v2 fused zero-fill+pool+layout)',
+            'kernel': '%s (bev_pool_v2 fused zero-fill+pool+layout)' % kname,
             'bound': 'hbm',
             'achieved': round(achieved, 1),
             'peak': HBM_PEAK_GBS,
             'unit': 'GB/s',
             'frac': round(achieved / HBM_PEAK_GBS, 4),
-            'traffic': traffic,
-            'traffic_source': traffic_source,
+            'traffic': traffic_of(pmc, kname) if args.workload == 'S2' else None,
+            'traffic_source': pmc_src,
             'algorithmic_bytes': alg,
             'kernel_ms': round(kernel_ms, 5),
+            'kernel_launches_timed': kiters,
         },
     }
-
+    if placed is not None:
+        pg = alg / (placed['kernel_ms'] * 1e-3) / 1e9
+        placed.update(achieved=round(pg, 1), frac=round(pg / HBM_PEAK_GBS, 4))
+        result['roofline']['placed'] = placed
     if percall is not None:
         result['percall_prepare'] = percall
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if solo and not args.no_sv and args.workload == 'S2':
+        try:
+            with torch.no_grad():
+                result['sv'] = sv_subobject(dev, pmc)
+        except Exception as e:  # report, do not hide
+            print('sv sub-object failed: %r' % (e,), file=sys.stderr)
+    if solo and not args.no_veonb and args.workload == 'S2':
+        try:
+            ms, stages, tf = veon_path(args, dev, 'vitb', (256, 704), 20, 3, None, 1)
+            result['veonb'] = {
+                'workload': 'VEONB (BASELINE configs[2]), 6-cam 256x704: ' +
+                            VEON_WHAT % ('ViT-B', 'ViT-B/16'),
+                'ms_per_step': round(ms, 4), 'samples_per_s': round(1e3 / ms, 2),
+                'steps': 20, 'dtype': 'bf16', 'stages_ms': stages,
+                'roofline': {'kernel': 'k_conv3d_k3 (8 launches, AlignNetOcc3D body)',
+                             'bound': 'mfma', 'achieved': round(tf, 1),
+                             'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                             'frac': round(tf / MFMA_PEAK_TFLOPS, 4)}}
+        except Exception as e:  # report, do not hide
+            print('veonb sub-object failed: %r' % (e,), file=sys.stderr)
+    if solo and not args.no_cpu_baseline:
         result['cpu_baseline'] = cpu_baseline(args, grid, input_size, n_cams, C,
                                               rig, depth5, feat5)
     if rank == 0:
@@ -403,10 +533,10 @@ def main():
 
 def cpu_baseline(args, grid, input_size, n_cams, C, rig, depth5, feat5):
     """The same step (pool with cached ranks -> (B,C,Z,Y,X)) by the pure-PyTorch
-    index_add_ port on the host cores.  The oracle is only the thing timed
-    here, never part of the product path."""
+    index_add_ port on the host cores, at the best of several torch thread
+    counts (a short probe each, then the sample at the winner).  The oracle is
+    only the thing timed here, never part of the product path."""
     from oracle import lss_torch
-    threads = torch.get_num_threads()
     lower, interval, gsize = lss_torch.grid_infos(grid)
     fr = lss_torch.make_frustum(grid['depth'], input_size, 16)
     cams = (rig['sensor2ego'], rig['intrins'], rig['post_rots'],
@@ -414,21 +544,38 @@ def cpu_baseline(args, grid, input_size, n_cams, C, rig, depth5, feat5):
     coor = lss_torch.lidar_coor(fr, *cams)
     ranks = lss_torch.voxel_prepare(coor, lower, interval, gsize)
     d, f = depth5.cpu(), feat5.cpu()
-    for _ in range(2):
+
+    def once():
         lss_torch.lift(fr, (lower, interval, gsize), cams, d, f, ranks=ranks)
+    ncpu = os.cpu_count() or 1
+    default_threads = torch.get_num_threads()
+    probes = {}
+    for n in sorted({t for t in (8, 16, 32, 64, 128, default_threads) if t <= max(ncpu, 8)}):
+        torch.set_num_threads(n)
+        once()
+        t0, k = time.perf_counter(), 0
+        while time.perf_counter() - t0 < 1.5:
+            once()
+            k += 1
+        probes[n] = k / (time.perf_counter() - t0)
+    best = max(probes, key=probes.get)
+    torch.set_num_threads(best)
     n, t0 = 0, time.perf_counter()
     while True:
-        lss_torch.lift(fr, (lower, interval, gsize), cams, d, f, ranks=ranks)
+        once()
         n += 1
         el = time.perf_counter() - t0
-        if el > args.cpu_seconds or n >= 200:
+        if el > args.cpu_seconds or n >= 400:
             break
+    torch.set_num_threads(default_threads)
     return {
-        'value': round(n / el, 3), 'unit': 'samples/s', 'cores': threads,
+        'value': round(n / el, 3), 'unit': 'samples/s', 'cores': best,
         'kind': 'port',
         'sample': '%d iterations (%.1f s) of oracle.lss_torch.lift with cached '
-                  'ranks on the %s workload, torch %d threads, fp32'
-                  % (n, el, args.workload, threads),
+                  'ranks on the %s workload, torch %d threads (best of %s by a 1.5 s '
+                  'probe each: %s samples/s), fp32'
+                  % (n, el, args.workload, best, sorted(probes),
+                     {k: round(v, 2) for k, v in sorted(probes.items())}),
     }
 
 

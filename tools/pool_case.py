@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Run ONE pool kernel case in a loop (for rocprofv3 passes):
     python tools/pool_case.py SV rows_mp_bf16 [dbg] [iters]
+    python tools/pool_case.py ALL        (the dominant kernels of S2 and SV, 10 launches each)
 cases: rows_mp_bf16 (padded), rows_mp_f32, rows_cf_f32, rows_cf_bf16, slab_cf_f32."""
 import os
 import sys
@@ -15,9 +16,18 @@ from veon_amd.ops.bev_pool_v2 import bev_pool as bp  # noqa: E402
 
 
 def main():
+    if sys.argv[1] == 'ALL':   # what bench.py's PMC child passes run
+        for tag, case in (('S2', 'slab_cf_f32'), ('SV', 'rows_cf_f32'), ('SV', 'rows_mp_f32'),
+                          ('SV', 'rows_mp_bf16')):
+            run(tag, case, 0, 10)
+        return
     tag, case = sys.argv[1], sys.argv[2]
     dbg = int(sys.argv[3]) if len(sys.argv) > 3 else 0
     iters = int(sys.argv[4]) if len(sys.argv) > 4 else 20
+    run(tag, case, dbg, iters)
+
+
+def run(tag, case, dbg, iters):
     grid, size, cams, C = {'S2': (synthetic.GRID_S2, (256, 704), 6, 80),
                            'SV': (synthetic.GRID_VEON, (512, 1408), 6, 256)}[tag]
     dev = torch.device('cuda:0')
