@@ -227,17 +227,29 @@ def sv_subobject(dev, pmc):
 
 
 def veon_path(args, dev, encoder, size, steps, warmup, dist, world):
-    """One chained occupancy-path workload -> (ms per step, stage dict, body TFLOP/s)."""
+    """One chained occupancy-path workload -> (ms per step, stage dict, body
+    TFLOP/s, launch mode).  The timed step is the whole forward replayed from ONE
+    hipGraph (BASELINE configs[4]: "hipGraph-captured forward") unless capture
+    fails or --no-graph is given."""
     from tools import hotpath_bench
+    from veon_amd.graphs import GraphedCallable
     r = hotpath_bench.run_full(encoder, size, dev=str(dev), iters=5, verbose=False)
-    step = r['step']
+    step, launch = r['step'], 'eager, encoder branches on two streams'
+    if not args.no_graph:
+        try:
+            net, images, geom = r['net'], r['images'], r['geom']
+            graphed = GraphedCallable(lambda im: net(im, geom), (images,))
+            step = lambda: graphed.graph.replay()  # noqa: E731  (static input in place)
+            launch = 'one hipGraph of the whole forward'
+        except Exception as e:  # report, do not hide
+            print('whole-forward capture failed (%r); eager' % (e,), file=sys.stderr)
     with torch.no_grad():
         el = timed_steps(step, steps, warmup, dist, dev)
     ms = el / steps * 1e3
     body_flops = 8 * 2.0 * 8 * 100 * 100 * 256 * 256 * 27
     tf = body_flops / (r['body_ms'] * 1e-3) / 1e12
     stages = {k: round(v, 3) for k, v in r.items() if k.endswith('_ms')}
-    return ms, stages, tf
+    return ms, stages, tf, launch
 
 
 VEON_WHAT = ('the 3-D occupancy path of VeonTemporal.simple_test '
@@ -252,7 +264,8 @@ VEON_WHAT = ('the 3-D occupancy path of VeonTemporal.simple_test '
 def bench_hotpath(args, rank, world, dev, dist):
     """--workload VEONB / VEONL: the whole path as the timed step (replicas for N > 1)."""
     enc = 'vitb' if args.workload == 'VEONB' else 'vitl'
-    ms, stages, tf = veon_path(args, dev, enc, (256, 704), args.steps, args.warmup, dist, world)
+    ms, stages, tf, launch = veon_path(args, dev, enc, (256, 704), args.steps, args.warmup,
+                                       dist, world)
     if rank != 0:
         return
     print(json.dumps({
@@ -262,7 +275,8 @@ def bench_hotpath(args, rank, world, dev, dist):
         'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
         'config': {'workload': '%s, 6-cam 256x704: ' % args.workload +
                                VEON_WHAT % ('ViT-B' if enc == 'vitb' else 'ViT-L', 'ViT-B/16'),
-                   'parallelism': 'replicas x%d' % world, 'stages_ms': stages},
+                   'parallelism': 'replicas x%d' % world, 'launch': launch,
+                   'stages_ms': stages},
         'roofline': {'kernel': 'k_conv3d_k3 (8 launches, AlignNetOcc3D body)', 'bound': 'mfma',
                      'achieved': round(tf, 1), 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                      'frac': round(tf / MFMA_PEAK_TFLOPS, 4), 'traffic': None},
@@ -356,7 +370,7 @@ def main():
                         step()
                 torch.cuda.current_stream().wait_stream(s)
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
+                with torch.cuda.graph(graph, stream=s):   # the warm-up's stream
                     step()
             except Exception as e:  # report, do not hide
                 print('hipGraph capture failed (%s); running eager' % e,
@@ -428,7 +442,7 @@ def main():
                 step2()
             torch.cuda.current_stream().wait_stream(s2)
             g2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g2):
+            with torch.cuda.graph(g2, stream=s2):
                 step2()
             for _ in range(args.warmup):
                 g2.replay()
@@ -510,12 +524,12 @@ def main():
             print('sv sub-object failed: %r' % (e,), file=sys.stderr)
     if solo and not args.no_veonb and args.workload == 'S2':
         try:
-            ms, stages, tf = veon_path(args, dev, 'vitb', (256, 704), 20, 3, None, 1)
+            ms, stages, tf, launch = veon_path(args, dev, 'vitb', (256, 704), 20, 3, None, 1)
             result['veonb'] = {
                 'workload': 'VEONB (BASELINE configs[2]), 6-cam 256x704: ' +
                             VEON_WHAT % ('ViT-B', 'ViT-B/16'),
                 'ms_per_step': round(ms, 4), 'samples_per_s': round(1e3 / ms, 2),
-                'steps': 20, 'dtype': 'bf16', 'stages_ms': stages,
+                'steps': 20, 'dtype': 'bf16', 'launch': launch, 'stages_ms': stages,
                 'roofline': {'kernel': 'k_conv3d_k3 (8 launches, AlignNetOcc3D body)',
                              'bound': 'mfma', 'achieved': round(tf, 1),
                              'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',

@@ -1,0 +1,86 @@
+"""hipGraph capture / replay of the per-call lift and of the whole occupancy path
+(BASELINE configs[4]: "hipGraph-captured forward").  Round 1 had a lift graph fault
+on replay while a second graph was alive; the lift now allocates nothing and issues
+no memset inside a capture (static per-stream workspace, lss_prepare_hip.LiftWorkspace)
+and that situation is replayed here."""
+import pytest
+import torch
+
+from veon_amd import synthetic
+from veon_amd.graphs import GraphedCallable
+from veon_amd.models import build_neck
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+GRID = {'x': [-10.0, 10.0, 1.0], 'y': [-10.0, 10.0, 1.0], 'z': [-1.0, 3.0, 1.0],
+        'depth': [1.0, 13.0, 1.0]}
+
+
+def _lift_module(C, ds):
+    vt = build_neck(dict(type='LSSViewTransformerRaw', grid_config=GRID, input_size=(64, 176),
+                         out_channels=C, collapse_z=False, ds_feat=ds)).to(DEV).eval()
+    vt.sync_free = True
+    return vt
+
+
+def _inputs(C, D, seed):
+    g = torch.Generator().manual_seed(seed)
+    geom = [t.to(DEV) for t in synthetic.rig_inputs(synthetic.make_rig(1, 2, (64, 176)))]
+    feat = torch.randn(1, 2, C, 4, 11, generator=g).to(DEV)
+    depth = torch.softmax(torch.randn(1, 2, D, 4, 11, generator=g), 2).to(DEV)
+    return feat, depth, geom
+
+
+@pytest.mark.parametrize('C', [16, 256])
+def test_sync_free_lift_graph_replays_also_with_a_second_graph_alive(C):
+    vt = _lift_module(C, [2, 2, 2])
+    feat, depth, geom = _inputs(C, vt.D, 0)
+
+    def lift(f, d):
+        return vt([f] + geom, d)
+    with torch.no_grad():
+        want = lift(feat, depth).clone()
+        g1 = GraphedCallable(lift, (feat, depth))
+        assert torch.equal(g1(feat, depth), want)
+        # a second graph of another module, captured and replayed in between
+        vt2 = _lift_module(C, [1, 1, 1])
+        f2, d2, _ = _inputs(C, vt2.D, 1)
+        want2 = vt2([f2] + geom, d2).clone()
+        g2 = GraphedCallable(lambda f, d: vt2([f] + geom, d), (f2, d2))
+        assert torch.equal(g2(f2, d2), want2)
+        # the older graph again, with new inputs through its static tensors
+        f3, d3, _ = _inputs(C, vt.D, 2)
+        want3 = lift(f3, d3).clone()
+        assert torch.equal(g1(f3, d3), want3)
+        assert torch.equal(g2(f2, d2), want2)
+        assert torch.equal(g1(feat, depth), want)
+
+
+def test_whole_occupancy_path_replays_from_one_graph():
+    from veon_amd.models.veon_occ import VeonOccupancyPath
+    torch.manual_seed(0)
+    size, ncam = (64, 176), 2
+    net = VeonOccupancyPath(
+        input_size=size, num_cam=ncam, encoder='vitb', clip_width=64, clip_layers=4,
+        clip_heads=1, clip_first_tail=2, clip_proj_dim=64, embed_dim=64,
+        occ_size=(4, 20, 20), hsa_dim=64, hsa_fusion_map=('0->1->1', '1->2->2'),
+        grid_config=GRID).to(DEV).eval()
+    geom = [t.to(DEV) for t in synthetic.rig_inputs(synthetic.make_rig(1, ncam, size))]
+    images = torch.randn(1, ncam, 3, *size, device=DEV)
+    with torch.no_grad():
+        want = {k: v.clone() for k, v in net(images, geom).items()}
+        graphed = GraphedCallable(lambda im: net(im, geom), (images,))
+        for _ in range(2):
+            got = graphed(images)
+            for k in ('sem_occ', 'bin_occ'):
+                # MIOpen may pick other convolution algorithms under capture: bf16
+                # rounding level, not bit equality
+                err = (got[k].float() - want[k].float()).abs().max().item()
+                assert err <= 2e-2 * max(1.0, want[k].abs().max().item()), (k, err)
+        images2 = torch.randn_like(images)
+        want2 = {k: v.clone() for k, v in net(images2, geom).items()}
+        got2 = graphed(images2)
+        for k in ('sem_occ', 'bin_occ'):
+            err = (got2[k].float() - want2[k].float()).abs().max().item()
+            assert err <= 2e-2 * max(1.0, want2[k].abs().max().item()), (k, err)
+        assert (got2['sem_occ'] - want['sem_occ']).abs().max().item() > 0  # really new data

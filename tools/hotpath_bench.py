@@ -254,7 +254,7 @@ def run_full(enc='vitb', size=(256, 704), dev='cuda:0', iters=20, verbose=True):
             % (t_2, 1e3 / t_2))
     return dict(depth_branch_ms=t_d, semantic_branch_ms=t_s, hsa_ms=t_h, body_ms=t_b,
                 decoder_ms=t_1 - t_d - t_s, chained_one_stream_ms=t_1, chained_ms=t_2,
-                step=lambda: net(images, geom))
+                step=lambda: net(images, geom), net=net, images=images, geom=geom)
 
 
 def run_temporal(enc='vitb', size=(256, 704), T=1, dev='cuda:0', iters=10):

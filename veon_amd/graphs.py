@@ -26,6 +26,9 @@ class GraphedCallable:
     def __init__(self, fn, example_inputs, warmup=3):
         self.static_in = tuple(_map(t, lambda x: x.clone())
                                for t in example_inputs)
+        # warm-up and capture on the SAME stream: per-stream static workspaces
+        # (lss_prepare_hip.lift_workspace) and lazily built caches are then
+        # allocated before the capture starts, not inside it
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side), torch.no_grad():
@@ -33,7 +36,7 @@ class GraphedCallable:
                 fn(*self.static_in)
         torch.cuda.current_stream().wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(self.graph):
+        with torch.no_grad(), torch.cuda.graph(self.graph, stream=side):
             self.static_out = fn(*self.static_in)
 
     def __call__(self, *inputs):

@@ -128,8 +128,10 @@ class VeonOccupancyPath(nn.Module):
                 feats, supp = self.clip_features(img)
             depth = self.estimate_depth(img)
             cur.wait_stream(side)
-            for t in list(feats.values()) + [supp]:
-                t.record_stream(cur)
+            if not torch.cuda.is_current_stream_capturing():
+                # (a captured forward keeps every tensor of the capture alive)
+                for t in list(feats.values()) + [supp]:
+                    t.record_stream(cur)
         else:
             feats, supp = self.clip_features(img)
             depth = self.estimate_depth(img)

@@ -436,9 +436,10 @@ def bev_pool_v2_prepared(depth, feat, pre, bev_feat_shape, out=None):
     if getattr(pre, 'vstart', None) is not None and _rows_ok(C, feat=feat):
         return rows_forward(depth, feat, pre.ranks_depth, pre.ranks_feat, pre.vstart,
                             bev_feat_shape, out=out)
-    if pre.plan is None:  # voxel count not a multiple of the tile: build it now
-        pre.plan = build_plan(pre.ranks_bev, pre.interval_starts, B, Z * Y * X,
-                              attach=False, counts=pre.counts)
+    plan = pre.plan
+    if plan is None:  # voxel count not a multiple of the tile: built per call
+        plan = build_plan(pre.ranks_bev, pre.interval_starts, B, Z * Y * X,
+                          attach=False, counts=pre.counts)
     if out is None:
         out = torch.empty((B, C, Z, Y, X), dtype=torch.float32, device=dev)
     with _lib.on_device(dev):
@@ -447,7 +448,7 @@ def bev_pool_v2_prepared(depth, feat, pre, bev_feat_shape, out=None):
             _lib.ptr(feat), _feat_code(feat), _lib.ptr(pre.ranks_depth),
             _lib.ptr(pre.ranks_feat), _lib.ptr(pre.ranks_bev),
             _lib.ptr(pre.interval_starts), _lib.ptr(pre.interval_lengths),
-            _lib.ptr(pre.plan), _lib.ptr(out), _lib.LAYOUT_BCZYX,
+            _lib.ptr(plan), _lib.ptr(out), _lib.LAYOUT_BCZYX,
             _lib.stream_ptr(dev))
     _lib.check(st, 'veon_bev_pool_v2_fwd_fused_ex')
     return out
