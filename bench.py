@@ -262,21 +262,43 @@ VEON_WHAT = ('the 3-D occupancy path of VeonTemporal.simple_test '
 
 
 def bench_hotpath(args, rank, world, dev, dist):
-    """--workload VEONB / VEONL: the whole path as the timed step (replicas for N > 1)."""
+    """--workload VEONB / VEONL: the whole path as the timed step.  --shard replicas
+    (default): one sample per GPU, no collective (BASELINE configs[4]); --shard
+    cameras: the six cameras of ONE sample over the ranks, encoders per shard, one
+    RCCL all-reduce of the voxel feature volume (configs[3])."""
     enc = 'vitb' if args.workload == 'VEONB' else 'vitl'
-    ms, stages, tf, launch = veon_path(args, dev, enc, (256, 704), args.steps, args.warmup,
-                                       dist, world)
+    clip = 'ViT-B/16' if enc == 'vitb' else 'ViT-L/14-336'
+    if args.shard == 'cameras':
+        from tools import hotpath_bench
+        r = hotpath_bench.run_full(enc, (256, 704), dev=str(dev), iters=3, verbose=False)
+        net, images, geom = r['net'], r['images'], r['geom']
+        rd = torch.bfloat16 if os.environ.get('VEON_REDUCE_DTYPE', 'bf16') == 'bf16' else None
+
+        def step():
+            return net.forward_camera_sharded(images, geom, reduce_dtype=rd)
+        with torch.no_grad():
+            el = timed_steps(step, args.steps, args.warmup, dist, dev)
+        ms = el / args.steps * 1e3
+        stages = {k: round(v, 3) for k, v in r.items() if k.endswith('_ms')}
+        tf = 8 * 2.0 * 8 * 100 * 100 * 256 * 256 * 27 / (r['body_ms'] * 1e-3) / 1e12
+        launch = 'eager; all-reduce of the un-pooled volume in %s' % (
+            'bf16' if rd is not None else 'fp32')
+        value, scaling = 1e3 / ms, 'strong'
+        par = 'cameras of one sample sharded over %d GPUs + RCCL all-reduce' % world
+    else:
+        ms, stages, tf, launch = veon_path(args, dev, enc, (256, 704), args.steps,
+                                           args.warmup, dist, world)
+        value, scaling, par = world * 1e3 / ms, 'weak', 'replicas x%d' % world
     if rank != 0:
         return
     print(json.dumps({
-        'metric': '6cam_hotpath_samples_per_sec', 'value': round(world * 1e3 / ms, 2),
+        'metric': '6cam_hotpath_samples_per_sec', 'value': round(value, 2),
         'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-        'ms_per_step': round(ms, 4), 'higher_is_better': True, 'scaling': 'weak',
+        'ms_per_step': round(ms, 4), 'higher_is_better': True, 'scaling': scaling,
         'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
         'config': {'workload': '%s, 6-cam 256x704: ' % args.workload +
-                               VEON_WHAT % ('ViT-B' if enc == 'vitb' else 'ViT-L', 'ViT-B/16'),
-                   'parallelism': 'replicas x%d' % world, 'launch': launch,
-                   'stages_ms': stages},
+                               VEON_WHAT % ('ViT-B' if enc == 'vitb' else 'ViT-L', clip),
+                   'parallelism': par, 'launch': launch, 'stages_ms': stages},
         'roofline': {'kernel': 'k_conv3d_k3 (8 launches, AlignNetOcc3D body)', 'bound': 'mfma',
                      'achieved': round(tf, 1), 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                      'frac': round(tf / MFMA_PEAK_TFLOPS, 4), 'traffic': None},

@@ -99,3 +99,114 @@ def test_slice_cameras_keeps_per_sample_tensors():
     assert li[1].shape[:2] == (2, 3) and li[5].shape[:2] == (2, 3)
     assert li[6].shape == (2, 3, 3)          # bda is per sample
     assert torch.equal(li[3], inp[3][:, 2:5])
+
+
+def test_collapsed_and_squeezed_volumes_are_unfolded_not_zeroed():
+    """with collapse_z=True (the default of both view transformers) the
+    lift returns (B, C*Z, Y, X); the sharded wrapper used to replace it by zeros."""
+    B, C, Z, Y, X = 2, 3, 4, 5, 6
+    vol = torch.arange(B * C * Z * Y * X, dtype=torch.float32).view(B, C, Z, Y, X)
+    collapsed = torch.cat(vol.unbind(dim=2), 1)
+    got = sharding.CameraShardedLift._as_volume(collapsed, (B, C, Z, Y, X))
+    assert torch.equal(got, vol)
+    sq = vol[:, :, :1]
+    assert torch.equal(sharding.CameraShardedLift._as_volume(sq.squeeze(2), (B, C, 1, Y, X)), sq)
+    dummy = torch.zeros(B, C * Z, X, Y)
+    assert not sharding.CameraShardedLift._as_volume(dummy, (B, C, Z, Y, X)).any()
+    with pytest.raises(ValueError):
+        sharding.CameraShardedLift._as_volume(torch.ones(B, C * Z, X, Y), (B, C, Z, Y, X))
+    with pytest.raises(ValueError):
+        sharding.CameraShardedLift._as_volume(torch.zeros(B, C, Z, Y), (B, C, Z, Y, X))
+
+
+def test_default_lift_with_collapse_z(monkeypatch):
+    """_default_lift through a collapse_z=True transformer (its lift replaced by the
+    CPU oracle): the collapsed volume is unfolded before the reduce / max-pool."""
+    rig = synthetic.make_rig(1, 2, SIZE)
+    vt = build_neck(dict(type='LSSViewTransformerRaw', grid_config=GRID, input_size=SIZE,
+                         out_channels=4, collapse_z=True, ds_feat=[1, 1, 1]))
+    depth, feat = synthetic.make_depth_feat(1, 2, vt.D, 4, 4, 11, seed=1)
+    inp = [feat] + list(synthetic.rig_inputs(rig))
+
+    def fake_view_transform(input, d, tran_feat):
+        B, N, C, H, W = input[0].shape
+        full = _oracle_lift(vt, input, d.view(B, N, -1, H, W))
+        return torch.cat(full.unbind(dim=2), 1)           # what collapse_z returns
+    monkeypatch.setattr(vt, 'view_transform', fake_view_transform)
+    out = sharding.CameraShardedLift(vt)(inp, depth)
+    assert torch.equal(out, _oracle_lift(vt, inp, depth))
+
+
+# ---------------------------------------------------------------------------
+# the whole occupancy path, cameras sharded (BASELINE configs[3]) -- tiny widths
+# ---------------------------------------------------------------------------
+PGRID = {'x': [-10.0, 10.0, 1.0], 'y': [-10.0, 10.0, 1.0], 'z': [-1.0, 3.0, 1.0],
+         'depth': [1.0, 13.0, 1.0]}
+
+
+def _tiny_path(ncam):
+    from veon_amd.models.veon_occ import VeonOccupancyPath
+    torch.manual_seed(0)
+    net = VeonOccupancyPath(
+        input_size=SIZE, num_cam=ncam, encoder='vitb', clip_width=64, clip_layers=4,
+        clip_heads=1, clip_first_tail=2, clip_proj_dim=64, embed_dim=16,
+        occ_size=(4, 20, 20), hsa_dim=64, hsa_fusion_map=('0->1->1', '1->2->2'),
+        grid_config=PGRID, bf16_heads=False, two_streams=False).eval()
+    vt = net.view_transformer
+
+    def cpu_view_transform(input, depth, tran_feat):   # the lift: CPU oracle
+        B, N, C, H, W = input[0].shape
+        grid = (vt.grid_lower_bound, vt.grid_interval, vt.grid_size)
+        cams = (input[1], input[3], input[4], input[5], input[6])
+        return lss_torch.lift(vt.frustum, grid, cams, depth.view(B, N, -1, H, W),
+                              tran_feat.view(B, N, C, H, W))
+    vt.view_transform = cpu_view_transform
+    geom = list(synthetic.rig_inputs(synthetic.make_rig(1, ncam, SIZE)))
+    images = torch.randn(1, ncam, 3, *SIZE, generator=torch.Generator().manual_seed(1))
+    return net, images, geom
+
+
+def _path_worker(rank, world, port, ncam, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(2)
+        net, images, geom = _tiny_path(ncam)
+        with torch.no_grad():
+            out = net.forward_camera_sharded(images, geom)
+            full = net.from_volume(net.lift_cameras(images, geom, 0, ncam))
+        gathered = [torch.empty_like(out['sem_occ']) for _ in range(world)]
+        dist.all_gather(gathered, out['sem_occ'])
+        same = all(torch.equal(g, out['sem_occ']) for g in gathered)
+        errs = {k: (out[k].float() - full[k].float()).abs().max().item()
+                for k in ('sem_occ', 'bin_occ')}
+        scale = {k: full[k].abs().max().item() for k in ('sem_occ', 'bin_occ')}
+        cls = (out['occ_pred_cls'] != full['occ_pred_cls']).float().mean().item()
+        q.put((rank, same, errs, scale, cls, tuple(out['sem_occ'].shape)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world,ncam', [(2, 3), (3, 2)])
+def test_camera_sharded_occupancy_path_matches_unsharded(world, ncam):
+    """Each rank: encoders + HSA + fusion + lift of its cameras -> all-reduce of the
+    un-pooled volume -> max-pool -> body / heads / classifier; equals the unsharded
+    path up to the reduce's summation order; ranks without a camera add zeros."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_path_worker, args=(r, world, port, ncam, q))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, same, errs, scale, cls, shape in res:
+        assert shape == (1, 17, 4, 20, 20)
+        assert same, rank
+        for k in errs:   # fp32 modules on CPU: only the reduce's summation order differs
+            assert errs[k] <= 1e-4 * max(scale[k], 1.0), (rank, k, errs[k], scale[k])
+        assert cls < 0.01

@@ -226,7 +226,9 @@ def run_full(enc='vitb', size=(256, 704), dev='cuda:0', iters=20, verbose=True):
         if verbose:
             print(*a, flush=True)
     torch.manual_seed(0)
-    net = VeonOccupancyPath(input_size=size, encoder=enc).to(dev).eval()
+    # 'vitl' = VEON-L: CLIP ViT-L/14-336 (K = 18 of 24) + DepthAnythingV2 ViT-L
+    kw = dict(VeonOccupancyPath.VEON_L) if enc == 'vitl' else dict(encoder=enc)
+    net = VeonOccupancyPath(input_size=size, **kw).to(dev).eval()
     geom = [t.to(dev) for t in synthetic.rig_inputs(synthetic.make_rig(1, 6, size))]
     images = torch.randn(1, 6, 3, *size, device=dev)
     img = images.flatten(0, 1)

@@ -239,11 +239,13 @@ class ClipVisualTrunk(nn.Module):
         a convolution library call."""
         p = self.patch_size
         N, C, H, W = x.shape
-        if (self.training or torch.is_grad_enabled() or H % p or W % p):
+        if self.training or torch.is_grad_enabled():
             x = self.conv1(x)
             _, _, h, w = x.shape
             return x.flatten(2).permute(0, 2, 1), (h, w)
         h, w = H // p, W // p
+        if H % p or W % p:   # a stride-p conv without padding never reads the remainder
+            x = x[:, :, :h * p, :w * p].contiguous()     # (ViT-L/14 on 128 x 352: 9 x 25)
         cols = x.view(N, C, h, p, w, p).permute(0, 2, 4, 1, 3, 5).reshape(N * h * w, C * p * p)
         out = cols @ self.conv1.weight.view(self.conv1.out_channels, -1).t()
         return out.view(N, h * w, -1), (h, w)

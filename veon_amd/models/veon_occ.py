@@ -40,12 +40,20 @@ from .semantic_net.hsa_network import HighresSideAdaptorNetwork
 
 
 class VeonOccupancyPath(nn.Module):
+    # VEON-L (configs[3]/[4]): SAN on CLIP ViT-L/14-336 + DepthAnythingV2 ViT-L
+    # (semantic_net/configs/san_clip_vit_large_res4_coco_temporal.yaml:5-6,15:
+    # K = 18 of 24 blocks, 16 heads, HSA fusion map 0->3->6 / 1->9->12 / 2->15->18,
+    # lifting layer 24, CLIP projection 768; clip_utils/visual.py:31-52)
+    VEON_L = dict(encoder='vitl', clip_width=1024, clip_layers=24, clip_heads=16,
+                  clip_first_tail=18, clip_proj_dim=768, clip_patch=14, clip_image=336,
+                  hsa_fusion_map=('0->3->6', '1->9->12', '2->15->18'))
+
     def __init__(self, input_size=(256, 704), grid_config=None, num_cam=6,
                  encoder='vitb', n_classes=17, clip_width=768, clip_layers=12,
                  clip_heads=12, clip_first_tail=9, clip_proj_dim=512, embed_dim=256,
                  occ_size=(16, 200, 200), bf16_heads=True, two_streams=True,
                  hsa_dim=384, hsa_fusion_map=('0->3->3', '1->6->6', '2->9->9'),
-                 num_temporal=1):
+                 num_temporal=1, clip_patch=16, clip_image=224):
         super().__init__()
         from .. import synthetic
         grid_config = grid_config or synthetic.GRID_VEON
@@ -55,7 +63,8 @@ class VeonOccupancyPath(nn.Module):
                                  out_channels=[256, 512, 1024, 1024])}[encoder]
         self.depth_model = build_neck(dict(type='DepthAnythingV2Adaptor', max_depth=80.0,
                                            use_lora=True, lora_r=16, **dav2_cfg))
-        self.clip_trunk = ClipVisualTrunk(224, 16, clip_width, clip_layers, clip_heads)
+        self.clip_trunk = ClipVisualTrunk(clip_image, clip_patch, clip_width, clip_layers,
+                                          clip_heads)
         self.clip_first_tail = clip_first_tail
         self.ln_post = nn.LayerNorm(clip_width)
         self.clip_proj = nn.Parameter(torch.randn(clip_width, clip_proj_dim)
@@ -87,15 +96,16 @@ class VeonOccupancyPath(nn.Module):
         self.__dict__['_side'] = None
 
     # ------------------------------------------------------------- branches
-    def estimate_depth(self, img):
+    def estimate_depth(self, img, num_cam=None):
         """(B*N,3,H,W) -> metric depth (B, N, H/2, W/2) (veon_temporal.py:209-214;
         the reference resizes to 252x700 for any of its input sizes)."""
+        num_cam = num_cam or self.num_cam
         H, W = img.shape[-2:]
         x = F.interpolate(img, (252, 700), mode='bilinear', align_corners=False)
         d = self.depth_model(x)['metric_depth']
         d = F.interpolate(d[:, None], (H // 2, W // 2), mode='bilinear',
                           align_corners=True)[:, 0]
-        return d.view(-1, self.num_cam, H // 2, W // 2)
+        return d.view(-1, num_cam, H // 2, W // 2)
 
     def clip_features(self, img):
         """FeatureExtractor on the half-resolution image, HSA on the full one,
@@ -116,6 +126,7 @@ class VeonOccupancyPath(nn.Module):
         used instead of the depth encoder, as the reference's ``use_depth_pred``
         data pipeline does."""
         img = images.flatten(0, 1)
+        n_cam = images.shape[1]
         if depth is not None:
             feats, supp = self.clip_features(img)
             return feats, supp, depth.to(img.device, torch.float32)
@@ -126,7 +137,7 @@ class VeonOccupancyPath(nn.Module):
             side.wait_stream(cur)
             with torch.cuda.stream(side):
                 feats, supp = self.clip_features(img)
-            depth = self.estimate_depth(img)
+            depth = self.estimate_depth(img, n_cam)
             cur.wait_stream(side)
             if not torch.cuda.is_current_stream_capturing():
                 # (a captured forward keeps every tensor of the capture alive)
@@ -134,7 +145,7 @@ class VeonOccupancyPath(nn.Module):
                     t.record_stream(cur)
         else:
             feats, supp = self.clip_features(img)
-            depth = self.estimate_depth(img)
+            depth = self.estimate_depth(img, n_cam)
         return feats, supp, depth
 
     def lift_frame(self, images, img_metas, out_volume=None, depth=None):
@@ -165,6 +176,99 @@ class VeonOccupancyPath(nn.Module):
         vt = self.view_transformer
         return align_after_lss(volume, adj_metas, vt.grid_config, tuple(vt.ds))
 
+    def _tail(self, x, prev_volumes=None):
+        """Conv3d body -> heads -> classifier -> upsampling -> arg-max on a lifted
+        PaddedVolume (san_in_veon_temporal.py:196-211, veon_temporal.py:219-227)."""
+        dec = self.occ_decoder
+        if prev_volumes:
+            x = dec._temporal(x, prev_volumes)
+        x = dec.__dict__['_body'](x, return_volume=True)
+        bin_occ = dec.occupancy_pred(x)
+        feat = dec.feat_pred(x, return_volume=True)
+        return self._classify(bin_occ, feat)
+
+    def _classify(self, bin_occ, feat):
+        sem_occ = semantic_inference_3d_fused(self.ov_classifier_weight, feat, self.occ_size)
+        bin_occ = F.interpolate(bin_occ, size=tuple(self.occ_size), mode='trilinear',
+                                align_corners=False)
+        # veon_temporal.py:219-227
+        score, cls = torch.softmax(sem_occ, dim=1).max(dim=1)
+        keep = (score > 0.0) & (torch.softmax(bin_occ, dim=1)[:, 0] > 0.5)
+        occ = torch.where(keep, cls, torch.full_like(cls, sem_occ.shape[1]))
+        return {'bin_occ': bin_occ, 'sem_occ': sem_occ,
+                'occ_pred_cls': occ.permute(0, 3, 2, 1).contiguous()}
+
+    def lift_cameras(self, images, img_metas, lo, hi, depth=None):
+        """The UN-POOLED lifted volume (B, C, Z, Y, X) fp32 of cameras [lo, hi) of
+        the rig: both encoder branches, the HSA network and the fusion layer run on
+        those cameras only, then the lift (V = sum over cameras of V_cam, so the
+        volumes of disjoint camera sets add up to the full one; the 2x2x2 max-pool
+        does not commute with that sum and comes after it).  ``img_metas`` is the
+        calibration of the WHOLE rig: the key-ego frame is camera 0's
+        (align_net_occ3d.py:328-352)."""
+        B, N = images.shape[:2]
+        dec, vt = self.occ_decoder, self.view_transformer
+        metas = dec.prepare_meta(list(img_metas[:5]) + [img_metas[5][None]])
+        C = dec.layers_3d_body[0].conv1.conv.in_channels
+        x, y, z = (int(v) for v in vt.grid_size)
+        if hi <= lo:
+            return torch.zeros((B, C, z, y, x), dtype=torch.float32, device=images.device)
+        n = hi - lo
+        sub = None if depth is None else depth[:, lo:hi]
+        feats, supp, d = self._branches(images[:, lo:hi], sub)
+        depth2 = dec.prepare_depth(d)                      # (B, n, D, Hf, Wf)
+        hf, wf = self.input_size[0] // 16, self.input_size[1] // 16
+        src_clip, src_ec = dec.fusion_map[0]
+        fused = dec.fusion_layers['layer_0']([supp][src_ec], feats[src_clip], (hf, wf))
+        feats_2d = fused.reshape(B, n, fused.shape[1], hf, wf)
+        local = [t[:, lo:hi].contiguous() for t in metas[:5]] + [metas[5]]
+        vol = vt.view_transform([feats_2d] + local,
+                                depth2.reshape(B * n, -1, hf, wf),
+                                feats_2d.reshape(B * n, -1, hf, wf).float())
+        return vol if vol.dim() == 5 else vol.view(B, C, z, y, x)
+
+    def forward_camera_sharded(self, images, img_metas, group=None, reduce_dtype=None,
+                               depth=None):
+        """BASELINE configs[3]: the cameras of ONE sample sharded over the ranks of
+        ``group`` -- every rank runs the encoders / HSA / fusion / lift of its cameras
+        (``lift_cameras``), ONE all-reduce(SUM) of the full-resolution voxel feature
+        volume (RCCL over xGMI; ``reduce_dtype=torch.bfloat16`` halves the message),
+        then max-pool, Conv3d body, heads and classifier replicated on every rank.
+        Ranks beyond the camera count contribute zeros.  Same outputs as
+        ``forward`` up to the summation order of the all-reduce."""
+        import torch.distributed as dist
+        from .. import conv3d_ops, sharding
+        active = dist.is_available() and dist.is_initialized()
+        world = dist.get_world_size(group) if active else 1
+        rank = dist.get_rank(group) if active else 0
+        B, N = images.shape[:2]
+        lo, hi = sharding.camera_slices(N, world)[rank]
+        vol = self.lift_cameras(images, img_metas, lo, hi, depth)
+        if world > 1:
+            if reduce_dtype is not None and reduce_dtype != vol.dtype:
+                buf = vol.to(reduce_dtype)
+                dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+                vol = buf.float()
+            else:
+                dist.all_reduce(vol, op=dist.ReduceOp.SUM, group=group)
+        return self.from_volume(vol)
+
+    def from_volume(self, vol):
+        """Everything after the (reduced) un-pooled lifted volume (B, C, Z, Y, X):
+        ds_feat max-pool, Conv3d body, heads, classifier, arg-max."""
+        from .. import conv3d_ops
+        dz, dy, dx = self.view_transformer.ds
+        b, c, z, y, x = vol.shape
+        pooled = vol.view(b, c, z // dz, dz, y // dy, dy, x // dx, dx).amax(dim=(3, 5, 7))
+        dec = self.occ_decoder
+        if vol.is_cuda and dec._fast_path(pooled[:, :1, 0]):
+            lifted = dec._lift_volume(b, c, vol.device)
+            return self._tail(conv3d_ops.pack(pooled, out=lifted))
+        xx = pooled
+        for layer_3d in dec.layers_3d_body:
+            xx = layer_3d(xx)
+        return self._classify(dec.occupancy_pred(xx), dec.feat_pred(xx))
+
     def forward(self, images, img_metas, prev_volumes=None, depth=None):
         """images (B, N, 3, H, W); img_metas = (sensor2egos, ego2globals, intrins,
         post_rots, post_trans, bda) as the reference's ``img[1:7]``;
@@ -186,20 +290,6 @@ class VeonOccupancyPath(nn.Module):
                                    images.device)
             x = dec.fuse(0, None, feats, [supp], depth2, metas2, None, (hf, wf),
                          out_volume=vol)
-            if prev_volumes:
-                x = dec._temporal(x, prev_volumes)
-            x = dec.__dict__['_body'](x, return_volume=True)
-            bin_occ = dec.occupancy_pred(x)
-            feat = dec.feat_pred(x, return_volume=True)
-        else:
-            out = dec(sem_embed_ds, feats, [supp], depth, metas, prev_volumes)
-            bin_occ, feat = out['bin_occ'], out['feat_occ']
-        sem_occ = semantic_inference_3d_fused(self.ov_classifier_weight, feat, self.occ_size)
-        bin_occ = F.interpolate(bin_occ, size=tuple(self.occ_size), mode='trilinear',
-                                align_corners=False)
-        # veon_temporal.py:219-227
-        score, cls = torch.softmax(sem_occ, dim=1).max(dim=1)
-        keep = (score > 0.0) & (torch.softmax(bin_occ, dim=1)[:, 0] > 0.5)
-        occ = torch.where(keep, cls, torch.full_like(cls, sem_occ.shape[1]))
-        return {'bin_occ': bin_occ, 'sem_occ': sem_occ,
-                'occ_pred_cls': occ.permute(0, 3, 2, 1).contiguous()}
+            return self._tail(x, prev_volumes)
+        out = dec(sem_embed_ds, feats, [supp], depth, metas, prev_volumes)
+        return self._classify(out['bin_occ'], out['feat_occ'])

@@ -73,9 +73,7 @@ class CameraShardedLift(torch.nn.Module):
         shape = self._volume_shape(input)
         if vol is None:  # more ranks than cameras: contribute zeros
             vol = torch.zeros(shape, dtype=torch.float32, device=input[0].device)
-        if tuple(vol.shape) != tuple(shape):
-            # the reference's empty-grid dummy has another shape; use zeros
-            vol = torch.zeros(shape, dtype=torch.float32, device=input[0].device)
+        vol = self._as_volume(vol, shape)
         if world > 1:
             if self.reduce_dtype is not None and self.reduce_dtype != vol.dtype:
                 buf = vol.to(self.reduce_dtype)
@@ -90,6 +88,25 @@ class CameraShardedLift(torch.nn.Module):
             vol = vol.view(b, c, z // dz, dz, y // dy, dy, x // dx, dx) \
                 .amax(dim=(3, 5, 7))
         return vol
+
+    @staticmethod
+    def _as_volume(vol, shape):
+        """The lift's result as (B, C, Z, Y, X).  The view transformers may return
+        the volume with Z folded into the channels (``collapse_z``: index z*C + c,
+        view_transformer_raw.py:240-241), with a unit Z squeezed (the accelerate
+        branch, :325) or -- when no frustum point falls inside the grid -- the
+        reference's all-zero dummy of shape (B, C*Z, X, Y) (:221-231).  Anything else
+        is an error: silently contributing zeros would corrupt the reduced volume."""
+        B, C, Z, Y, X = shape
+        if tuple(vol.shape) == tuple(shape):
+            return vol
+        if vol.dim() == 4 and tuple(vol.shape) == (B, C * Z, Y, X):
+            return vol.view(B, Z, C, Y, X).permute(0, 2, 1, 3, 4).contiguous()
+        if vol.dim() == 4 and tuple(vol.shape) == (B, C * Z, X, Y) and not bool(vol.any()):
+            return vol.new_zeros(shape)     # the empty-grid dummy (X != Y)
+        raise ValueError('camera-sharded lift: the view transformer returned shape %r, '
+                         'expected %r (or its collapse_z / squeezed / empty-grid forms)'
+                         % (tuple(vol.shape), tuple(shape)))
 
     def _volume_shape(self, input):
         vt = self.vt
