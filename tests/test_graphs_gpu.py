@@ -84,3 +84,47 @@ def test_whole_occupancy_path_replays_from_one_graph():
             err = (got2[k].float() - want2[k].float()).abs().max().item()
             assert err <= 2e-2 * max(1.0, want2[k].abs().max().item()), (k, err)
         assert (got2['sem_occ'] - want['sem_occ']).abs().max().item() > 0  # really new data
+
+
+def test_camera_sharded_path_single_rank_equals_forward():
+    """forward_camera_sharded without a process group (one rank, all cameras) walks
+    lift_cameras -> un-pooled fp32 volume -> max-pool -> pack -> body; it must agree
+    with forward (fused pool + max-pool straight into the padded bf16 volume)."""
+    from veon_amd.models.veon_occ import VeonOccupancyPath
+    torch.manual_seed(0)
+    size, ncam = (64, 176), 2
+    net = VeonOccupancyPath(
+        input_size=size, num_cam=ncam, encoder='vitb', clip_width=64, clip_layers=4,
+        clip_heads=1, clip_first_tail=2, clip_proj_dim=64, embed_dim=64,
+        occ_size=(4, 20, 20), hsa_dim=64, hsa_fusion_map=('0->1->1', '1->2->2'),
+        grid_config=GRID).to(DEV).eval()
+    geom = [t.to(DEV) for t in synthetic.rig_inputs(synthetic.make_rig(1, ncam, size))]
+    images = torch.randn(1, ncam, 3, *size, device=DEV)
+    with torch.no_grad():
+        a = net(images, geom)
+        b = net.forward_camera_sharded(images, geom)
+        # two half-rigs add up to the whole (V = sum over cameras)
+        v = net.lift_cameras(images, geom, 0, 1) + net.lift_cameras(images, geom, 1, 2)
+        c = net.from_volume(v)
+    for k in ('sem_occ', 'bin_occ'):
+        scale = max(1.0, a[k].abs().max().item())
+        assert (a[k] - b[k]).abs().max().item() <= 2e-2 * scale, k
+        assert (a[k] - c[k]).abs().max().item() <= 2e-2 * scale, k
+
+
+def test_veon_l_preset_builds_and_runs_tiny_resolution():
+    """VEON-L wiring (CLIP ViT-L/14-336: patch 14, 24 layers, K = 18, 16 heads; DA-V2
+    ViT-L) on two cameras: the patch-14 trunk, HSA fusion map and tail run natively."""
+    from veon_amd.models.veon_occ import VeonOccupancyPath
+    torch.manual_seed(0)
+    size, ncam = (64, 176), 2
+    net = VeonOccupancyPath(input_size=size, num_cam=ncam, occ_size=(4, 20, 20),
+                            grid_config=GRID, embed_dim=64,
+                            **VeonOccupancyPath.VEON_L).to(DEV).eval()
+    assert len(net.clip_trunk.resblocks) == 24 and net.clip_trunk.patch_size == 14
+    geom = [t.to(DEV) for t in synthetic.rig_inputs(synthetic.make_rig(1, ncam, size))]
+    images = torch.randn(1, ncam, 3, *size, device=DEV)
+    with torch.no_grad():
+        out = net(images, geom)
+    assert out['sem_occ'].shape == (1, 17, 4, 20, 20)
+    assert torch.isfinite(out['sem_occ']).all() and torch.isfinite(out['bin_occ']).all()
