@@ -358,6 +358,9 @@ int veon_two_hot_depth(int BN, int H, int W, int ds, int D, float lo, float step
  *                      bias (optional) fp32 [.,.,T,T] with batch / head strides
  *                      in elements (0 = broadcast).  head_dim must be 64.
  */
+/* experiment knob of tools/gemm_bench.py: force the tile configuration of
+ * veon_vit_gemm (-1 = automatic, 0 = small-tile kernel, 1..6 = ring-kernel tiles) */
+void veon_gemm_ring_set(int config);
 int veon_vit_cast_bf16(const float *in, void *out_bf16, int64_t n, void *stream);
 int veon_vit_layernorm(const float *x, const float *gamma, const float *beta,
                        void *out_bf16, int T, int d, float eps, void *stream);

@@ -1,0 +1,84 @@
+#!/usr/bin/env python
+"""veon_vit_gemm tile configurations on the encoder shapes (M = 5406 tokens of a
+6-camera sample): small-tile kernel (0) and the ring-kernel tiles (1..6) against
+torch's bf16 linear (hipBLASLt), interleaved rounds, HIP-event timed, each checked
+against an fp32 reference on the bf16-rounded operands.
+
+    python tools/gemm_bench.py [rounds]
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from veon_amd import _lib, vit_ops  # noqa: E402
+
+SHAPES = [('B qkv', 5406, 2304, 768), ('B proj', 5406, 768, 768), ('B fc1', 5406, 3072, 768),
+          ('B fc2', 5406, 768, 3072), ('L qkv', 5406, 3072, 1024), ('L proj', 5406, 1024, 1024),
+          ('L fc1', 5406, 4096, 1024), ('L fc2', 5406, 1024, 4096),
+          ('clipB qkv', 1062, 2304, 768), ('clipB fc1', 1062, 3072, 768),
+          ('hsa head', 16896, 384, 384)]
+NAMES = {0: 'small', 1: '256x256', 2: '192x192', 3: '128x192', 4: '128x256', 5: '256x192',
+         6: '128x128', 7: '256x128'}
+NC = len(NAMES)
+
+
+def timeit(fn, iters=20):
+    for _ in range(3):
+        fn()
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3
+
+
+def main():
+    rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+    dev = 'cuda:0'
+    L = _lib.lib()
+    g = torch.Generator(device=dev).manual_seed(0)
+    for name, M, N, K in SHAPES:
+        a = (torch.rand(M, K, device=dev, generator=g) * 2 - 1).bfloat16()
+        w = ((torch.rand(N, K, device=dev, generator=g) * 2 - 1) * K ** -0.5).bfloat16()
+        b = torch.randn(N, device=dev, generator=g)
+        ref = a.float() @ w.float().t() + b
+        flops = 2.0 * M * N * K
+        res = {}
+        for cfg in range(NC):
+            L.veon_gemm_ring_set(cfg)
+            out = vit_ops.linear(a, w, b)
+            torch.cuda.synchronize()
+            err = (out.float() - ref).abs().max().item() / ref.abs().max().item()
+            res[cfg] = [err]
+        auto = None
+        for _ in range(rounds):
+            for cfg in range(NC):
+                L.veon_gemm_ring_set(cfg)
+                res[cfg].append(timeit(lambda: vit_ops.linear(a, w, b)))
+            L.veon_gemm_ring_set(-1)
+            t = timeit(lambda: vit_ops.linear(a, w, b))
+            auto = t if auto is None else min(auto, t)
+            res.setdefault('torch', [0.0]).append(
+                timeit(lambda: torch.nn.functional.linear(a, w, b.bfloat16())))
+        L.veon_gemm_ring_set(-1)
+        line = '%-10s %5dx%4dx%4d |' % (name, M, N, K)
+        for cfg in range(NC):
+            t = min(res[cfg][1:])
+            line += ' %s %6.1f%s' % (NAMES[cfg], t, '!' if res[cfg][0] > 1e-2 else '')
+        tt = min(res['torch'][1:])
+        best = min(range(NC), key=lambda c: min(res[c][1:]))
+        line += ' | auto %6.1f | torch %6.1f | best %s %.0f TF/s' % (
+            auto, tt, NAMES[best], flops / min(res[best][1:]) / 1e6)
+        print(line, flush=True)
+
+
+if __name__ == '__main__':
+    main()

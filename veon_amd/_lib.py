@@ -62,6 +62,7 @@ _SIGNATURES = {
     'veon_bev_pool_v2_fwd_maxpool': (_ci, [_ci] * 9 + [_vp] * 9 + [_vp]),
     'veon_downsample_depth': (_ci, [_ci] * 4 + [_vp, _vp, _vp]),
     'veon_two_hot_depth': (_ci, [_ci] * 5 + [_cf] * 3 + [_vp, _vp, _vp]),
+    'veon_gemm_ring_set': (None, [_ci]),
     'veon_vit_cast_bf16': (_ci, [_vp, _vp, _i64, _vp]),
     'veon_vit_layernorm': (_ci, [_vp, _vp, _vp, _vp, _ci, _ci, _cf, _vp]),
     'veon_vit_gemm': (_ci, [_vp] * 6 + [_ci] * 4 + [_vp]),

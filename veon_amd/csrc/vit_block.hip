@@ -18,6 +18,8 @@
 // V^T) as the MFMA "A" operand and the ACTIVATION (or Q, or P) as "B": the
 // accumulator then holds 4 consecutive output features of ONE token per lane
 // (16-byte epilogue accesses, per-token softmax statistics stay lane-local).
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "mfma_common.h"
@@ -281,6 +283,289 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_bf16(
         o[2] = (short)f2bf(v[2]); o[3] = (short)f2bf(v[3]);
         *reinterpret_cast<bf16x4*>(out + (int64_t)m * N + n) = o;
       }
+    }
+  }
+}
+
+// ------------------------------------------------- GEMM, big tiles + DMA ring
+// The 64/128-row tiles above move (1/BM + 1/BN) operand bytes per flop through
+// L2 -> LDS and re-read them from LDS at 1.25 / 0.75 fragment reads per MFMA:
+// at M = 5406 that, not the matrix pipe, sets their time (440 MB of L2 traffic
+// for the ViT-B qkv GEMM = the 34 us it takes).  This variant spends the
+// registers on the accumulator instead: a wave owns (16 MT) tokens x (16 NT)
+// features ((MT + NT) / (MT NT) fragment reads per MFMA: 0.375 for 8 x 4), a
+// workgroup of WM x WN = 8 waves a (WM 16 MT) x (WN 16 NT) tile, ONE workgroup
+// per CU, and the operands arrive through a ring of S LDS stages filled by
+// global_load_lds with S - 1 K-steps in flight: per K-step one counted
+// s_waitcnt vmcnt (never 0 in steady state), one raw s_barrier (LDS-DMA stays in
+// flight across it), the refill of the stage freed one step ago, then the
+// fragment reads and MFMAs of the step.  Same swizzled LDS image, fragment maps
+// and epilogues as k_gemm_bf16.
+template <int EPI>
+__device__ __forceinline__ void gemm_epilogue_store(f32x4 a, int m, int n, int N,
+                                                    const float* __restrict__ bias,
+                                                    const float* __restrict__ gamma,
+                                                    float* __restrict__ resid,
+                                                    bf16_t* __restrict__ out) {
+  float v[4] = {a[0], a[1], a[2], a[3]};
+  if (EPI == EPI_AFFINE || EPI == EPI_AFFINE_RELU) {
+    if (gamma != nullptr) {
+      const float4 g4 = *reinterpret_cast<const float4*>(gamma + n);
+      v[0] *= g4.x; v[1] *= g4.y; v[2] *= g4.z; v[3] *= g4.w;
+    }
+  }
+  if (bias != nullptr) {
+    const float4 b4 = *reinterpret_cast<const float4*>(bias + n);
+    v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+  }
+  if (EPI == EPI_RESID) {
+    float* rp = resid + (int64_t)m * N + n;
+    float4 r4 = *reinterpret_cast<const float4*>(rp);
+    if (gamma != nullptr) {
+      const float4 g4 = *reinterpret_cast<const float4*>(gamma + n);
+      v[0] *= g4.x; v[1] *= g4.y; v[2] *= g4.z; v[3] *= g4.w;
+    }
+    r4.x += v[0]; r4.y += v[1]; r4.z += v[2]; r4.w += v[3];
+    *reinterpret_cast<float4*>(rp) = r4;
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (EPI == EPI_GELU) v[k] = gelu_erf(v[k]);
+      if (EPI == EPI_QUICKGELU) v[k] = quick_gelu(v[k]);
+      if (EPI == EPI_AFFINE_RELU) v[k] = fmaxf(v[k], 0.f);
+    }
+    bf16x4 o;
+    o[0] = (short)f2bf(v[0]); o[1] = (short)f2bf(v[1]);
+    o[2] = (short)f2bf(v[2]); o[3] = (short)f2bf(v[3]);
+    *reinterpret_cast<bf16x4*>(out + (int64_t)m * N + n) = o;
+  }
+}
+
+// Two adjacent MFMA tiles whose weight rows were interleaved in groups of four
+// (see weight_row): a lane holds EIGHT consecutive features of one token, so the
+// epilogue moves 16 bytes of bf16 (32 of fp32) per lane and a wave instruction
+// covers whole 64-byte segments instead of 32-byte halves.
+template <int EPI>
+__device__ __forceinline__ void gemm_epilogue_store8(f32x4 a, f32x4 b, int m, int n, int N,
+                                                     const float* __restrict__ bias,
+                                                     const float* __restrict__ gamma,
+                                                     float* __restrict__ resid,
+                                                     bf16_t* __restrict__ out) {
+  if (n + 8 > N) {  // N % 8 == 4: the second half falls off the matrix
+    gemm_epilogue_store<EPI>(a, m, n, N, bias, gamma, resid, out);
+    return;
+  }
+  float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  auto scale8 = [&](const float* g) {
+    const float4 g0 = *reinterpret_cast<const float4*>(g + n);
+    const float4 g1 = *reinterpret_cast<const float4*>(g + n + 4);
+    v[0] *= g0.x; v[1] *= g0.y; v[2] *= g0.z; v[3] *= g0.w;
+    v[4] *= g1.x; v[5] *= g1.y; v[6] *= g1.z; v[7] *= g1.w;
+  };
+  // same order of operations as gemm_epilogue_store
+  if ((EPI == EPI_AFFINE || EPI == EPI_AFFINE_RELU) && gamma != nullptr) scale8(gamma);
+  if (bias != nullptr) {
+    const float4 b0 = *reinterpret_cast<const float4*>(bias + n);
+    const float4 b1 = *reinterpret_cast<const float4*>(bias + n + 4);
+    v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
+    v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+  }
+  if (EPI == EPI_RESID && gamma != nullptr) scale8(gamma);
+  if (EPI == EPI_RESID) {
+    float* rp = resid + (int64_t)m * N + n;
+    float4 r0 = *reinterpret_cast<const float4*>(rp);
+    float4 r1 = *reinterpret_cast<const float4*>(rp + 4);
+    r0.x += v[0]; r0.y += v[1]; r0.z += v[2]; r0.w += v[3];
+    r1.x += v[4]; r1.y += v[5]; r1.z += v[6]; r1.w += v[7];
+    *reinterpret_cast<float4*>(rp) = r0;
+    *reinterpret_cast<float4*>(rp + 4) = r1;
+  } else {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if (EPI == EPI_GELU) v[k] = gelu_erf(v[k]);
+      if (EPI == EPI_QUICKGELU) v[k] = quick_gelu(v[k]);
+      if (EPI == EPI_AFFINE_RELU) v[k] = fmaxf(v[k], 0.f);
+    }
+    uint4 o;
+    o.x = pack_bf16(v[0], v[1]);
+    o.y = pack_bf16(v[2], v[3]);
+    o.z = pack_bf16(v[4], v[5]);
+    o.w = pack_bf16(v[6], v[7]);
+    *reinterpret_cast<uint4*>(out + (int64_t)m * N + n) = o;
+  }
+}
+
+// Weight row (inside the wave's 16 NT feature rows) that MFMA tile t feeds as its
+// row r: tiles are paired, rows interleaved in groups of four, so that the
+// accumulator rows 4 fg .. 4 fg + 3 of tiles 2p and 2p+1 are the 8 consecutive
+// features 32 p + 8 fg + 0..7; an unpaired last tile keeps the plain order.
+template <int NT>
+__device__ __forceinline__ int weight_row(int t, int r) {
+  if (2 * (t / 2) + 1 < NT) return (t / 2) * 32 + (r / 4) * 8 + (t & 1) * 4 + (r & 3);
+  return t * 16 + r;
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  static_assert(N >= 0 && N < 64, "vmcnt is 6 bits");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int EPI, int WM, int WN, int MT, int NT, int S>
+__global__ __launch_bounds__(64 * WM * WN) void k_gemm_ring(
+    const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
+    const float* __restrict__ bias, const float* __restrict__ gamma,
+    float* __restrict__ resid, bf16_t* __restrict__ out, int M, int N, int K,
+    int grid_n, int abl) {
+  constexpr int NW = WM * WN;
+  constexpr int BM = WM * 16 * MT, TBN = WN * 16 * NT;
+  constexpr int A_ELEMS = BM * BK, STAGE_ELEMS = (BM + TBN) * BK;
+  constexpr int PIECES = (BM + TBN) / 8;  // 1 KiB DMA pieces per stage
+  static_assert(PIECES % NW == 0, "every wave issues the same number of pieces");
+  constexpr int P = PIECES / NW;           // per wave and stage
+  static_assert(P * (S - 1) < 64, "vmcnt range");
+  extern __shared__ __attribute__((aligned(16))) bf16_t smem[];  // [S][A | W]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  // blocks b and b + 8 share an XCD (speed only): give every XCD a contiguous run
+  // of tiles, neighbours in n first, so that the token rows a tile row re-reads
+  // stay in one L2
+  const int nwg = gridDim.x;
+  const int q8 = nwg / 8, r8 = nwg % 8, xcd = blockIdx.x % 8;
+  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) +
+                 blockIdx.x / 8;
+  const int m0 = (wg / grid_n) * BM, n0 = (wg % grid_n) * TBN;
+  const int fr = lane & 15, fg = lane >> 4;
+
+  // DMA map: piece p = wave + j*NW covers LDS rows 8p .. 8p+7 of the stage image
+  // (token rows first, then weight rows); lane l lands in row 8p + l/8, physical
+  // chunk l%8, so it fetches logical chunk (l%8) ^ (row & 7).
+  const bf16_t* src[P];
+#pragma unroll
+  for (int j = 0; j < P; ++j) {
+    const int r = (wave + j * NW) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ (r & 7);
+    if (r < BM) {
+      const int gm = m0 + r < M ? m0 + r : M - 1;
+      src[j] = A + (int64_t)gm * K + c * 8;
+    } else {
+      const int gn = n0 + (r - BM) < N ? n0 + (r - BM) : N - 1;
+      src[j] = W + (int64_t)gn * K + c * 8;
+    }
+  }
+  auto dma = [&](int stage, int k0) {
+    bf16_t* d = smem + stage * STAGE_ELEMS;
+#pragma unroll
+    for (int j = 0; j < P; ++j)
+      __builtin_amdgcn_global_load_lds((gptr_t)(src[j] + k0),
+                                       (lptr_t)(d + (wave + j * NW) * 512), 16, 0, 0);
+  };
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int offA[MT], offW[NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int ra = wm * (16 * MT) + i * 16 + fr;
+    offA[i] = ra * BK + ((fg ^ (ra & 7)) * 8);
+  }
+#pragma unroll
+  for (int i = 0; i < NT; ++i) {
+    const int rw = wn * (16 * NT) + weight_row<NT>(i, fr);
+    offW[i] = A_ELEMS + rw * BK + ((fg ^ (rw & 7)) * 8);
+  }
+
+  const int nk = K / BK;
+  // prologue: S - 1 stages in flight (fewer when K is short)
+#pragma unroll
+  for (int t = 0; t < S - 1; ++t)
+    if (t < nk) dma(t, t * BK);
+  // With S >= 3 the refill of a K-step is not issued as one burst behind the
+  // barrier (every wave would sit in the memory pipe's issue queue while the
+  // matrix pipe idles) but one piece after every MPP MFMAs: the queued MFMAs
+  // cover the issue slot of the DMA.  The refilled stage is needed two barriers
+  // later, so its late pieces still have a whole K-step to land.
+  constexpr bool ILV = S >= 3;
+  constexpr int MFMAS = 2 * MT * NT;
+  static_assert(MFMAS >= P, "at least one MFMA per DMA piece");
+  constexpr int MPP = MFMAS / P;
+  for (int kt = 0; kt < nk; ++kt) {
+    // my pieces of K-step kt have landed when at most S - 2 younger stages are
+    // outstanding; at the tail fewer were issued, so drain
+    if (kt + S - 1 <= nk) wait_vmcnt<P * (S - 2)>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();  // everyone's pieces landed, stage kt-1 is free
+    const bool refill = (kt + S - 1 < nk) && !(abl & 2);
+    const int rstage = (kt + S - 1) % S, rk0 = (kt + S - 1) * BK;
+    if (!ILV && refill) dma(rstage, rk0);
+    const bf16_t* st = smem + (kt % S) * STAGE_ELEMS;
+    if (abl & 8) {
+      if (ILV && refill) dma(rstage, rk0);
+      continue;
+    }
+    bf16_t* rd = smem + rstage * STAGE_ELEMS;
+#pragma unroll
+    for (int ks = 0; ks < BK / 32; ++ks) {
+      bf16x8 fw[NT], fa[MT];
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+        fw[j] = *reinterpret_cast<const bf16x8*>(st + (offW[j] ^ (ks * 32)));
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+        fa[i] = *reinterpret_cast<const bf16x8*>(st + (offA[i] ^ (ks * 32)));
+      if (abl & 4) {  // ablation: fragment reads only
+#pragma unroll
+        for (int j = 0; j < NT; ++j) asm volatile("" ::"v"(fw[j]));
+#pragma unroll
+        for (int i = 0; i < MT; ++i) asm volatile("" ::"v"(fa[i]));
+        if (ILV && refill && ks == 0) dma(rstage, rk0);
+        continue;
+      }
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i], acc[i][j],
+                                                               0, 0, 0);
+          if (ILV) {
+            const int c = ks * MT * NT + i * NT + j;  // compile-time after unrolling
+            if (c % MPP == MPP - 1 && c / MPP < P) {
+              const int jj = c / MPP;
+              if (refill)
+                __builtin_amdgcn_global_load_lds((gptr_t)(src[jj] + rk0),
+                                                 (lptr_t)(rd + (wave + jj * NW) * 512), 16,
+                                                 0, 0);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+        }
+    }
+  }
+  if (abl & 1) {  // ablation: no epilogue stores
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) asm volatile("" ::"v"(acc[i][j]));
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int m = m0 + wm * (16 * MT) + i * 16 + fr;
+    if (m >= M) continue;
+#pragma unroll
+    for (int p2 = 0; p2 < NT / 2; ++p2) {
+      const int n = n0 + wn * (16 * NT) + p2 * 32 + fg * 8;
+      if (n >= N) continue;
+      gemm_epilogue_store8<EPI>(acc[i][2 * p2], acc[i][2 * p2 + 1], m, n, N, bias, gamma,
+                                resid, out);
+    }
+    if (NT & 1) {
+      const int n = n0 + wn * (16 * NT) + (NT - 1) * 16 + fg * 4;
+      if (n < N)
+        gemm_epilogue_store<EPI>(acc[i][NT - 1], m, n, N, bias, gamma, resid, out);
     }
   }
 }
@@ -641,6 +926,29 @@ extern "C" int veon_layernorm_f32_to_padded(const float* x, const float* gamma,
                             stream);
 }
 
+namespace {
+int g_gemm_ring = -1;  // tools/gemm_bench.py: force a ring config (0 = small-tile kernel)
+int g_gemm_abl = 0;    // ablation bits of the ring kernel (0 in production)
+
+// Ring-kernel tile for a problem: 0 = keep the small-tile kernel.  Measured on
+// MI355X at the encoder shapes (tools/gemm_bench.py, profiles/r02_gemm_bench.txt):
+// the big tiles win where ONE round of workgroups fills most of the 256 CUs --
+// 256 x 256 for the ViT-B qkv projection (29.6 vs 32.7 us), 256 x 128 for N = 1024
+// (ViT-L proj / fc2) and for the HSA token heads (12.0 vs 16.1 us); with a second,
+// mostly empty round or far fewer workgroups than CUs the 64/128-row tiles (three
+// workgroups per CU, finer tail) stay ahead.
+inline int gemm_ring_config(int M, int N, int K) {
+  if ((int64_t)M * N < (int64_t)1 << 21 || K < 256) return 0;
+  auto wgs = [&](int bm, int bn) {
+    return (int64_t)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
+  };
+  const int64_t lo = 160, hi = kNumCU;
+  if (wgs(256, 256) >= lo && wgs(256, 256) <= hi) return 1;
+  if (wgs(256, 128) >= lo && wgs(256, 128) <= hi) return 7;
+  return 0;
+}
+}  // namespace
+
 extern "C" {
 
 int veon_vit_cast_bf16(const float* in, void* out, int64_t n, void* stream) {
@@ -673,6 +981,12 @@ int veon_vit_layernorm(const float* x, const float* gamma, const float* beta,
   return launch_status();
 }
 
+void veon_gemm_ring_set(int config) {
+  g_gemm_ring = config & 0xff;
+  if (config < 0) g_gemm_ring = -1;
+  g_gemm_abl = config < 0 ? 0 : (config >> 8);
+}
+
 int veon_vit_gemm(const void* a_bf16, const void* w_bf16, const float* bias,
                   const float* gamma, float* resid, void* out_bf16, int M, int N,
                   int K, int epilogue, void* stream) {
@@ -694,6 +1008,54 @@ int veon_vit_gemm(const void* a_bf16, const void* w_bf16, const float* bias,
   // more, smaller waves beat the 4-wave tiles of the same size by 5-10 %,
   // 256-wide 16-wave tiles and 160/192-row tiles that bring N = 768 down to one
   // round of workgroups were 10-20 % slower.
+  // Big-tile ring kernel (k_gemm_ring) for the encoder-sized problems: the tile is
+  // picked per shape so that the workgroups fill the 256 CUs in one or two rounds.
+  {
+    // (the fp32 read-modify-write of the residual epilogue, issued by every
+    // workgroup at the same time in a one-round grid, costs the big tiles more
+    // than their main loop gains: measured 30 vs 25 us on the ViT-L proj)
+    const int sel = g_gemm_ring >= 0 ? g_gemm_ring
+                    : epilogue == EPI_RESID ? 0 : gemm_ring_config(M, N, K);
+    if (sel > 0) {
+#define VEON_RING(EPI, WM, WN, MT, NT, S)                                             \
+  do {                                                                                \
+    constexpr int bm_ = WM * 16 * MT, bn_ = WN * 16 * NT;                             \
+    constexpr int lds = S * (bm_ + bn_) * BK * (int)sizeof(bf16_t);                   \
+    static const hipError_t attr = hipFuncSetAttribute(                               \
+        reinterpret_cast<const void*>(&k_gemm_ring<EPI, WM, WN, MT, NT, S>),          \
+        hipFuncAttributeMaxDynamicSharedMemorySize, lds);                             \
+    if (attr != hipSuccess) return VEON_ERR_LAUNCH;                                   \
+    const int gn = (N + bn_ - 1) / bn_, gm = (M + bm_ - 1) / bm_;                     \
+    hipLaunchKernelGGL((k_gemm_ring<EPI, WM, WN, MT, NT, S>), dim3((unsigned)(gn * gm)), \
+                       dim3(64 * WM * WN), lds, s, A, W, bias, gamma, resid, O, M, N, \
+                       K, gn, g_gemm_abl);                                            \
+  } while (0)
+#define VEON_RING_SEL(EPI)                                          \
+  do {                                                              \
+    switch (sel) {                                                  \
+      case 1: VEON_RING(EPI, 2, 4, 8, 4, 2); break; /* 256 x 256 */ \
+      case 2: VEON_RING(EPI, 2, 4, 6, 3, 3); break; /* 192 x 192 */ \
+      case 3: VEON_RING(EPI, 2, 4, 4, 3, 3); break; /* 128 x 192 */ \
+      case 4: VEON_RING(EPI, 2, 4, 4, 4, 3); break; /* 128 x 256 */ \
+      case 5: VEON_RING(EPI, 2, 4, 8, 3, 2); break; /* 256 x 192 */ \
+      case 7: VEON_RING(EPI, 4, 2, 4, 4, 3); break; /* 256 x 128 */ \
+      default: VEON_RING(EPI, 2, 4, 4, 2, 4); break; /* 128 x 128 */ \
+    }                                                               \
+  } while (0)
+      switch (epilogue) {
+        case EPI_BF16: VEON_RING_SEL(EPI_BF16); break;
+        case EPI_GELU: VEON_RING_SEL(EPI_GELU); break;
+        case EPI_QUICKGELU: VEON_RING_SEL(EPI_QUICKGELU); break;
+        case EPI_RESID: VEON_RING_SEL(EPI_RESID); break;
+        case EPI_AFFINE: VEON_RING_SEL(EPI_AFFINE); break;
+        case EPI_AFFINE_RELU: VEON_RING_SEL(EPI_AFFINE_RELU); break;
+        default: return VEON_ERR_BAD_ARG;
+      }
+#undef VEON_RING_SEL
+#undef VEON_RING
+      return launch_status();
+    }
+  }
   const int wm = 4, wn = 2;
   const int mt = ((int64_t)((M + 63) / 64) * ((N + 127) / 128) > 8 * kNumCU) ? 2 : 1;
   const int bm = wm * 16 * mt, bn = 64 * wn;
