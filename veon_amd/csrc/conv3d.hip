@@ -136,7 +136,10 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv3d_k3(
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int rw = wn * 64 + i * 16 + fr;
+    // tiles are paired, weight rows interleaved in groups of four: the accumulator
+    // rows 4 fg .. 4 fg + 3 of tiles 2p and 2p + 1 are the 8 consecutive features
+    // 32 p + 8 fg + 0..7 (16-byte epilogue accesses instead of 8-byte ones)
+    const int rw = wn * 64 + (i / 2) * 32 + (fr / 4) * 8 + (i & 1) * 4 + (fr & 3);
     offW[i] = rw * CBK + ((fg ^ (rw & 7)) * 8);
   }
 
@@ -171,7 +174,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv3d_k3(
     __syncthreads();  // next slab landed (vmcnt drained) and this one released
   }
 
-  // epilogue: lane owns 4 consecutive features of one voxel per tile
+  // epilogue: lane owns 8 consecutive features of one voxel per tile pair
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     const int m = m0 + wm * (16 * MT) + i * 16 + fr;
@@ -181,32 +184,38 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv3d_k3(
     const bool interior = (kd == 1 || (z >= 1 && z <= Zp - 2)) && y >= 1 &&
                           y <= Yp - 2 && x >= 1 && x <= Xp - 2;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = n0 + wn * 64 + j * 16 + fg * 4;
+    for (int p2 = 0; p2 < 2; ++p2) {
+      const int n = n0 + wn * 64 + p2 * 32 + fg * 8;  // Cout % 8 == 0
       if (n >= Cout) continue;
-      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      const f32x4 a0 = acc[i][2 * p2], a1 = acc[i][2 * p2 + 1];
+      float v[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
       if (scale != nullptr) {
-        const float4 s4 = *reinterpret_cast<const float4*>(scale + n);
-        v[0] *= s4.x; v[1] *= s4.y; v[2] *= s4.z; v[3] *= s4.w;
+        const float4 s0 = *reinterpret_cast<const float4*>(scale + n);
+        const float4 s1 = *reinterpret_cast<const float4*>(scale + n + 4);
+        v[0] *= s0.x; v[1] *= s0.y; v[2] *= s0.z; v[3] *= s0.w;
+        v[4] *= s1.x; v[5] *= s1.y; v[6] *= s1.z; v[7] *= s1.w;
       }
       if (shift != nullptr) {
-        const float4 b4 = *reinterpret_cast<const float4*>(shift + n);
-        v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+        const float4 b0 = *reinterpret_cast<const float4*>(shift + n);
+        const float4 b1 = *reinterpret_cast<const float4*>(shift + n + 4);
+        v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
+        v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
       }
       if (RESID) {
-        const bf16x4 r4 =
-            *reinterpret_cast<const bf16x4*>(resid + (int64_t)m * Cout + n);
+        const bf16x8 r8 =
+            *reinterpret_cast<const bf16x8*>(resid + (int64_t)m * Cout + n);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] += bf2f((bf16_t)r4[k]);
+        for (int k = 0; k < 8; ++k) v[k] += bf2f((bf16_t)r8[k]);
       }
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
+      for (int k = 0; k < 8; ++k) {
         if (ACT == 1) v[k] = fmaxf(v[k], 0.f);
         if (ACT == 2) v[k] = gelu_erf(v[k]);
         if (!interior) v[k] = 0.f;
       }
-      const uint2 o = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
-      *reinterpret_cast<uint2*>(out + (int64_t)m * Cout + n) = o;
+      const uint4 o = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]),
+                       pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])};
+      *reinterpret_cast<uint4*>(out + (int64_t)m * Cout + n) = o;
     }
   }
 }

@@ -136,171 +136,6 @@ __device__ __forceinline__ float quick_gelu(float x) {
 }
 
 
-template <int EPI, int WM, int WN, int MT>
-__global__ __launch_bounds__(64 * WM * WN) void k_gemm_bf16(
-    const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
-    const float* __restrict__ bias, const float* __restrict__ gamma,
-    float* __restrict__ resid, bf16_t* __restrict__ out, int M, int N, int K) {
-  // one array for all staging (a second __shared__ object beside a DMA target
-  // can make hipcc drain vmcnt before every ds_read: guide section 5 item 4a)
-  constexpr int BM = WM * 16 * MT;      // tile height
-  constexpr int TBN = 64 * WN;          // tile width
-  constexpr int NW = WM * WN;           // waves
-  constexpr int A_ELEMS = BM * BK;      // activation slab per buffer
-  constexpr int TW_ELEMS = TBN * BK;    // weight slab per buffer
-  constexpr int BUF_ELEMS = A_ELEMS + TW_ELEMS;
-  constexpr int APIECES = BM / 8, WPIECES = TBN / 8;  // 1 KiB DMA pieces
-  constexpr int AP = (APIECES + NW - 1) / NW, WP = (WPIECES + NW - 1) / NW;
-  extern __shared__ __attribute__((aligned(16))) bf16_t smem[];  // [2][A|W]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / WN, wn = wave % WN;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * TBN;
-  const int fr = lane & 15, fg = lane >> 4;
-
-  // DMA map: a wave instruction fills 64 LDS chunks = 8 rows of a slab; the
-  // pieces of each slab are dealt round-robin to the waves (wave w issues pieces
-  // w, w + NW, ...); lane l lands in row r = 8*piece + l/8, physical chunk l%8,
-  // so it must fetch logical chunk (l%8) ^ (r&7).  Rows beyond M / N are
-  // clamped (their outputs are dropped).
-  const bf16_t* srcA[AP];
-  const bf16_t* srcW[WP];
-#pragma unroll
-  for (int j = 0; j < AP; ++j) {
-    const int r = (wave + j * NW) * 8 + (lane >> 3);
-    const int c = (lane & 7) ^ (r & 7);
-    const int gm = m0 + r < M ? m0 + r : M - 1;
-    srcA[j] = A + (int64_t)gm * K + c * 8;
-  }
-#pragma unroll
-  for (int j = 0; j < WP; ++j) {
-    const int r = (wave + j * NW) * 8 + (lane >> 3);
-    const int c = (lane & 7) ^ (r & 7);
-    const int gn = n0 + r < N ? n0 + r : N - 1;
-    srcW[j] = W + (int64_t)gn * K + c * 8;
-  }
-  auto dma = [&](int buf, int k0) {
-    bf16_t* dA = smem + buf * BUF_ELEMS;
-    bf16_t* dW = dA + A_ELEMS;
-#pragma unroll
-    for (int j = 0; j < AP; ++j)
-      if (wave + j * NW < APIECES)  // wave-uniform
-        __builtin_amdgcn_global_load_lds((gptr_t)(srcA[j] + k0),
-                                         (lptr_t)(dA + (wave + j * NW) * 512), 16, 0, 0);
-#pragma unroll
-    for (int j = 0; j < WP; ++j)
-      if (wave + j * NW < WPIECES)
-        __builtin_amdgcn_global_load_lds((gptr_t)(srcW[j] + k0),
-                                         (lptr_t)(dW + (wave + j * NW) * 512), 16, 0, 0);
-  };
-
-  f32x4 acc[MT][4];  // [token tile][feature tile]
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  // fragment read offsets (bf16 elements) for ks = 0; ks = 1 flips chunk bit 2
-  int offA[MT], offW[4];
-#pragma unroll
-  for (int i = 0; i < MT; ++i) {
-    const int ra = wm * (16 * MT) + i * 16 + fr;
-    offA[i] = ra * BK + ((fg ^ (ra & 7)) * 8);
-  }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int rw = wn * 64 + i * 16 + fr;
-    offW[i] = rw * BK + ((fg ^ (rw & 7)) * 8);
-  }
-
-  const int nk = K / BK;
-  dma(0, 0);
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nk) dma(buf ^ 1, (kt + 1) * BK);
-    const bf16_t* tA = smem + buf * BUF_ELEMS;
-    const bf16_t* tW = tA + A_ELEMS;
-#pragma unroll
-    for (int ks = 0; ks < BK / 32; ++ks) {
-      bf16x8 fa[MT], fw[4];
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-        fa[i] = *reinterpret_cast<const bf16x8*>(tA + (offA[i] ^ (ks * 32)));
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        fw[j] = *reinterpret_cast<const bf16x8*>(tW + (offW[j] ^ (ks * 32)));
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          // weight rows as MFMA "A", token rows as "B":
-          // acc[i][j][reg] = C[token i*16 + fr][feature j*16 + 4*fg + reg]
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i],
-                                                               acc[i][j], 0, 0, 0);
-    }
-    __syncthreads();  // next slab landed (vmcnt drained) and this one released
-  }
-
-  // epilogue: lane owns 4 consecutive features of one token per tile
-#pragma unroll
-  for (int i = 0; i < MT; ++i) {
-    const int m = m0 + wm * (16 * MT) + i * 16 + fr;
-    if (m >= M) continue;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = n0 + wn * 64 + j * 16 + fg * 4;
-      if (n >= N) continue;
-      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-      if (EPI == EPI_AFFINE || EPI == EPI_AFFINE_RELU) {
-        // C*gamma + bias: a folded eval-mode BatchNorm after a 1x1 convolution
-        if (gamma != nullptr) {
-          const float4 g4 = *reinterpret_cast<const float4*>(gamma + n);
-          v[0] *= g4.x; v[1] *= g4.y; v[2] *= g4.z; v[3] *= g4.w;
-        }
-      }
-      if (bias != nullptr) {
-        const float4 b4 = *reinterpret_cast<const float4*>(bias + n);
-        v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
-      }
-      if (EPI == EPI_RESID) {
-        float* rp = resid + (int64_t)m * N + n;
-        float4 r4 = *reinterpret_cast<const float4*>(rp);
-        if (gamma != nullptr) {
-          const float4 g4 = *reinterpret_cast<const float4*>(gamma + n);
-          v[0] *= g4.x; v[1] *= g4.y; v[2] *= g4.z; v[3] *= g4.w;
-        }
-        r4.x += v[0]; r4.y += v[1]; r4.z += v[2]; r4.w += v[3];
-        *reinterpret_cast<float4*>(rp) = r4;
-      } else {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          if (EPI == EPI_GELU) v[k] = gelu_erf(v[k]);
-          if (EPI == EPI_QUICKGELU) v[k] = quick_gelu(v[k]);
-          if (EPI == EPI_AFFINE_RELU) v[k] = fmaxf(v[k], 0.f);
-        }
-        bf16x4 o;
-        o[0] = (short)f2bf(v[0]); o[1] = (short)f2bf(v[1]);
-        o[2] = (short)f2bf(v[2]); o[3] = (short)f2bf(v[3]);
-        *reinterpret_cast<bf16x4*>(out + (int64_t)m * N + n) = o;
-      }
-    }
-  }
-}
-
-// ------------------------------------------------- GEMM, big tiles + DMA ring
-// The 64/128-row tiles above move (1/BM + 1/BN) operand bytes per flop through
-// L2 -> LDS and re-read them from LDS at 1.25 / 0.75 fragment reads per MFMA:
-// at M = 5406 that, not the matrix pipe, sets their time (440 MB of L2 traffic
-// for the ViT-B qkv GEMM = the 34 us it takes).  This variant spends the
-// registers on the accumulator instead: a wave owns (16 MT) tokens x (16 NT)
-// features ((MT + NT) / (MT NT) fragment reads per MFMA: 0.375 for 8 x 4), a
-// workgroup of WM x WN = 8 waves a (WM 16 MT) x (WN 16 NT) tile, ONE workgroup
-// per CU, and the operands arrive through a ring of S LDS stages filled by
-// global_load_lds with S - 1 K-steps in flight: per K-step one counted
-// s_waitcnt vmcnt (never 0 in steady state), one raw s_barrier (LDS-DMA stays in
-// flight across it), the refill of the stage freed one step ago, then the
-// fragment reads and MFMAs of the step.  Same swizzled LDS image, fragment maps
-// and epilogues as k_gemm_bf16.
 template <int EPI>
 __device__ __forceinline__ void gemm_epilogue_store(f32x4 a, int m, int n, int N,
                                                     const float* __restrict__ bias,
@@ -405,6 +240,141 @@ __device__ __forceinline__ int weight_row(int t, int r) {
   return t * 16 + r;
 }
 
+template <int EPI, int WM, int WN, int MT>
+__global__ __launch_bounds__(64 * WM * WN) void k_gemm_bf16(
+    const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
+    const float* __restrict__ bias, const float* __restrict__ gamma,
+    float* __restrict__ resid, bf16_t* __restrict__ out, int M, int N, int K) {
+  // one array for all staging (a second __shared__ object beside a DMA target
+  // can make hipcc drain vmcnt before every ds_read: guide section 5 item 4a)
+  constexpr int BM = WM * 16 * MT;      // tile height
+  constexpr int TBN = 64 * WN;          // tile width
+  constexpr int NW = WM * WN;           // waves
+  constexpr int A_ELEMS = BM * BK;      // activation slab per buffer
+  constexpr int TW_ELEMS = TBN * BK;    // weight slab per buffer
+  constexpr int BUF_ELEMS = A_ELEMS + TW_ELEMS;
+  constexpr int APIECES = BM / 8, WPIECES = TBN / 8;  // 1 KiB DMA pieces
+  constexpr int AP = (APIECES + NW - 1) / NW, WP = (WPIECES + NW - 1) / NW;
+  extern __shared__ __attribute__((aligned(16))) bf16_t smem[];  // [2][A|W]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * TBN;
+  const int fr = lane & 15, fg = lane >> 4;
+
+  // DMA map: a wave instruction fills 64 LDS chunks = 8 rows of a slab; the
+  // pieces of each slab are dealt round-robin to the waves (wave w issues pieces
+  // w, w + NW, ...); lane l lands in row r = 8*piece + l/8, physical chunk l%8,
+  // so it must fetch logical chunk (l%8) ^ (r&7).  Rows beyond M / N are
+  // clamped (their outputs are dropped).
+  const bf16_t* srcA[AP];
+  const bf16_t* srcW[WP];
+#pragma unroll
+  for (int j = 0; j < AP; ++j) {
+    const int r = (wave + j * NW) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ (r & 7);
+    const int gm = m0 + r < M ? m0 + r : M - 1;
+    srcA[j] = A + (int64_t)gm * K + c * 8;
+  }
+#pragma unroll
+  for (int j = 0; j < WP; ++j) {
+    const int r = (wave + j * NW) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ (r & 7);
+    const int gn = n0 + r < N ? n0 + r : N - 1;
+    srcW[j] = W + (int64_t)gn * K + c * 8;
+  }
+  auto dma = [&](int buf, int k0) {
+    bf16_t* dA = smem + buf * BUF_ELEMS;
+    bf16_t* dW = dA + A_ELEMS;
+#pragma unroll
+    for (int j = 0; j < AP; ++j)
+      if (wave + j * NW < APIECES)  // wave-uniform
+        __builtin_amdgcn_global_load_lds((gptr_t)(srcA[j] + k0),
+                                         (lptr_t)(dA + (wave + j * NW) * 512), 16, 0, 0);
+#pragma unroll
+    for (int j = 0; j < WP; ++j)
+      if (wave + j * NW < WPIECES)
+        __builtin_amdgcn_global_load_lds((gptr_t)(srcW[j] + k0),
+                                         (lptr_t)(dW + (wave + j * NW) * 512), 16, 0, 0);
+  };
+
+  f32x4 acc[MT][4];  // [token tile][feature tile]
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // fragment read offsets (bf16 elements) for ks = 0; ks = 1 flips chunk bit 2
+  int offA[MT], offW[4];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int ra = wm * (16 * MT) + i * 16 + fr;
+    offA[i] = ra * BK + ((fg ^ (ra & 7)) * 8);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int rw = wn * 64 + weight_row<4>(i, fr);
+    offW[i] = rw * BK + ((fg ^ (rw & 7)) * 8);
+  }
+
+  const int nk = K / BK;
+  dma(0, 0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) dma(buf ^ 1, (kt + 1) * BK);
+    const bf16_t* tA = smem + buf * BUF_ELEMS;
+    const bf16_t* tW = tA + A_ELEMS;
+#pragma unroll
+    for (int ks = 0; ks < BK / 32; ++ks) {
+      bf16x8 fa[MT], fw[4];
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+        fa[i] = *reinterpret_cast<const bf16x8*>(tA + (offA[i] ^ (ks * 32)));
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        fw[j] = *reinterpret_cast<const bf16x8*>(tW + (offW[j] ^ (ks * 32)));
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          // weight rows as MFMA "A", token rows as "B":
+          // acc[i][j][reg] = C[token i*16 + fr][feature j*16 + 4*fg + reg]
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i],
+                                                               acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();  // next slab landed (vmcnt drained) and this one released
+  }
+
+  // epilogue: tiles are paired (weight_row): a lane owns 8 consecutive features
+  // of one token per pair -> 16-byte bf16 / 32-byte fp32 accesses
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int m = m0 + wm * (16 * MT) + i * 16 + fr;
+    if (m >= M) continue;
+#pragma unroll
+    for (int p2 = 0; p2 < 2; ++p2) {
+      const int n = n0 + wn * 64 + p2 * 32 + fg * 8;
+      if (n >= N) continue;
+      gemm_epilogue_store8<EPI>(acc[i][2 * p2], acc[i][2 * p2 + 1], m, n, N, bias, gamma,
+                                resid, out);
+    }
+  }
+}
+
+// ------------------------------------------------- GEMM, big tiles + DMA ring
+// The 64/128-row tiles above move (1/BM + 1/BN) operand bytes per flop through
+// L2 -> LDS and re-read them from LDS at 1.25 / 0.75 fragment reads per MFMA:
+// at M = 5406 that, not the matrix pipe, sets their time (440 MB of L2 traffic
+// for the ViT-B qkv GEMM = the 34 us it takes).  This variant spends the
+// registers on the accumulator instead: a wave owns (16 MT) tokens x (16 NT)
+// features ((MT + NT) / (MT NT) fragment reads per MFMA: 0.375 for 8 x 4), a
+// workgroup of WM x WN = 8 waves a (WM 16 MT) x (WN 16 NT) tile, ONE workgroup
+// per CU, and the operands arrive through a ring of S LDS stages filled by
+// global_load_lds with S - 1 K-steps in flight: per K-step one counted
+// s_waitcnt vmcnt (never 0 in steady state), one raw s_barrier (LDS-DMA stays in
+// flight across it), the refill of the stage freed one step ago, then the
+// fragment reads and MFMAs of the step.  Same swizzled LDS image, fragment maps
+// and epilogues as k_gemm_bf16.
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   static_assert(N >= 0 && N < 64, "vmcnt is 6 bits");
