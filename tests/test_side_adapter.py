@@ -1,0 +1,137 @@
+"""SAN's 2-D mask branch: ``RegionwiseSideAdapterNetwork`` +
+``MLPMaskDecoder`` + the hand-over to the CLIP recognition head against a vector made
+by the reference's own classes (oracle/tools/gen_golden_side_adapter.py).
+
+Pinned: query / position tokens, bicubic position resize, AddFusion points, mask
+decoder, attention-bias hand-over, 2-D semantic inference.  UNPINNED: timm's ViT
+block and open_clip's residual block (both absent from the build image) -- the same
+restatement runs on both sides of this comparison."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.conftest import load_golden
+from veon_amd.models.semantic_net import (ClipRecHead, ClipVisualTrunk,
+                                          RegionwiseSideAdapterNetwork, semantic_branch_2d)
+
+CFG = dict(clip_width=64, clip_layers=4, clip_heads=2, clip_first_tail=3, clip_proj_dim=24,
+           width=48, depth=4, heads=3, queries=5, vit_image=64)
+
+
+def _sub(g, prefix):
+    return {k[len(prefix):]: torch.from_numpy(v) for k, v in g.items() if k.startswith(prefix)}
+
+
+def _build(g):
+    W, K = CFG['clip_width'], CFG['clip_first_tail']
+    trunk = ClipVisualTrunk(image_size=32, patch_size=16, width=W, layers=CFG['clip_layers'],
+                            heads=CFG['clip_heads'])
+    trunk.load_state_dict(_sub(g, 'trunk/'), strict=True)
+    ln_post = torch.nn.LayerNorm(W)
+    ln_post.load_state_dict(_sub(g, 'ln_post/'), strict=True)
+    proj = torch.nn.Parameter(torch.from_numpy(g['clip_proj']))
+    head = ClipRecHead(trunk.resblocks, ln_post, proj, first_layer_idx=K,
+                       sos_token_num=CFG['queries'])
+    net = RegionwiseSideAdapterNetwork.build(
+        clip_dim=W, image_size=CFG['vit_image'], width=CFG['width'], depth=CFG['depth'],
+        num_heads=CFG['heads'], num_queries=CFG['queries'],
+        fusion_map=('0->0', '1->1', '2->2', '3->3'), deep_supervision_idxs=(4,),
+        attn_heads=CFG['clip_heads'], embed_channels=16, mlp_channels=24, mlp_num_layers=3)
+    net.load_state_dict(_sub(g, 'net/'), strict=True)      # reference parameter names
+    return trunk.eval(), head.eval(), net.eval()
+
+
+def _clip_feats(trunk, images, K):
+    x = F.interpolate(images, scale_factor=0.5, mode='bilinear', align_corners=False)
+    outs, hw = trunk(x, last_layer_idx=K)
+    feats = {}
+    for i, t in enumerate(outs):
+        ClipRecHead._save(feats, i, t, hw)
+    return feats
+
+
+def _close(a, ref, tol=1e-4):
+    err = np.abs(a.detach().cpu().float().numpy() - ref).max()
+    assert err <= tol * max(1.0, np.abs(ref).max()), err
+
+
+def test_side_adapter_matches_reference_classes():
+    g = load_golden('side_adapter_tiny')
+    trunk, head, net = _build(g)
+    images = torch.from_numpy(g['images'])
+    with torch.no_grad():
+        feats = _clip_feats(trunk, images, CFG['clip_first_tail'])
+        for i in range(CFG['clip_first_tail'] + 1):
+            _close(feats[i], g['clip_feat_%d' % i])
+        mask_preds, attn_biases, san_feats = net(images, feats)
+    assert len(mask_preds) == 1 and len(attn_biases) == 1 and len(attn_biases[0]) == 1
+    _close(mask_preds[0], g['mask_preds'])
+    _close(attn_biases[0][0], g['attn_bias'])
+    assert len(san_feats) == CFG['depth']
+    for i, f in enumerate(san_feats):
+        _close(f, g['san_feat_%d' % i])
+
+
+def test_2d_branch_matches_reference_chain():
+    g = load_golden('side_adapter_tiny')
+    trunk, head, net = _build(g)
+    images = torch.from_numpy(g['images'])
+    ov = torch.from_numpy(g['ov_classifier_weight'])
+    with torch.no_grad():
+        out = semantic_branch_2d(net, head, ov, images,
+                                 _clip_feats(trunk, images, CFG['clip_first_tail']))
+    for k in ('mask_embs', 'mask_logits', 'sem_seg_ds', 'sem_embed_ds', 'sem_seg'):
+        _close(out[k], g[k])
+
+
+def test_default_build_is_the_san_configuration():
+    """configs/san_config.py:58-75 / timm_wrapper.py:67-74: width 240, 8 blocks,
+    6 heads, patch 16, 100 queries, CLIP maps 0/3/6/9 fused before blocks 0..3."""
+    net = RegionwiseSideAdapterNetwork.build()
+    assert net.num_features == 240 and len(net.vit_model.blocks) == 8
+    assert net.vit_model.blocks[0].attn.num_heads == 6
+    assert net.query_embed.shape == (1, 100, 240)
+    assert net.fusion_map == {0: 0, 1: 3, 2: 6, 3: 9}
+    assert net.vit_model.pos_embed.shape == (1, 40 * 40, 240)
+    assert net.mask_decoder.total_heads == 12
+
+
+def test_path_exposes_the_2d_branch():
+    from veon_amd.models.veon_occ import VeonOccupancyPath
+    grid = {'x': [-10.0, 10.0, 1.0], 'y': [-10.0, 10.0, 1.0], 'z': [-1.0, 3.0, 1.0],
+            'depth': [1.0, 13.0, 1.0]}
+    kw = dict(input_size=(64, 96), num_cam=2, clip_width=64, clip_layers=4, clip_heads=2,
+              clip_first_tail=3, clip_proj_dim=24, embed_dim=64, n_classes=5,
+              occ_size=(4, 20, 20), hsa_dim=64, hsa_fusion_map=('0->1->1', '1->2->2'),
+              grid_config=grid, bf16_heads=False, two_streams=False, clip_image=32)
+    with pytest.raises(RuntimeError):
+        VeonOccupancyPath(**kw).forward_2d(torch.zeros(1, 2, 3, 64, 96))
+    net = VeonOccupancyPath(side_adapter=dict(
+        image_size=64, width=48, depth=4, num_heads=3, num_queries=5,
+        fusion_map=('0->0', '1->1', '2->2', '3->3'), deep_supervision_idxs=(4,),
+        embed_channels=16, mlp_channels=24), **kw).eval()
+    with torch.no_grad():
+        out = net.forward_2d(torch.randn(1, 2, 3, 64, 96))
+    assert out['mask_preds'].shape == (2, 5, 4, 6)
+    assert out['sem_embed_ds'].shape == (2, 24, 4, 6)
+    assert out['sem_seg'].shape == (2, 4, 64, 96)
+    assert torch.isfinite(out['sem_seg']).all()
+
+
+@pytest.mark.gpu
+def test_2d_branch_on_the_gpu():
+    """Same chain on cuda:0: the CLIP trunk runs on the bf16 MFMA kernels there, the
+    side adapter in fp32 PyTorch.  Tolerance 3e-2 of the output range (bf16 operands,
+    fp32 accumulation, 4 residual blocks)."""
+    g = load_golden('side_adapter_tiny')
+    trunk, head, net = _build(g)
+    dev = torch.device('cuda:0')
+    trunk, head, net = trunk.to(dev), head.to(dev), net.to(dev)
+    images = torch.from_numpy(g['images']).to(dev)
+    ov = torch.from_numpy(g['ov_classifier_weight']).to(dev)
+    with torch.no_grad():
+        out = semantic_branch_2d(net, head, ov, images,
+                                 _clip_feats(trunk, images, CFG['clip_first_tail']))
+    for k in ('mask_preds', 'sem_seg_ds', 'sem_embed_ds', 'sem_seg'):
+        _close(out[k], g[k], tol=3e-2)

@@ -53,7 +53,7 @@ class VeonOccupancyPath(nn.Module):
                  clip_heads=12, clip_first_tail=9, clip_proj_dim=512, embed_dim=256,
                  occ_size=(16, 200, 200), bf16_heads=True, two_streams=True,
                  hsa_dim=384, hsa_fusion_map=('0->3->3', '1->6->6', '2->9->9'),
-                 num_temporal=1, clip_patch=16, clip_image=224):
+                 num_temporal=1, clip_patch=16, clip_image=224, side_adapter=None):
         super().__init__()
         from .. import synthetic
         grid_config = grid_config or synthetic.GRID_VEON
@@ -71,6 +71,18 @@ class VeonOccupancyPath(nn.Module):
                                       * clip_width ** -0.5)
         self.clip_rec_head = ClipRecHead(self.clip_trunk.resblocks, self.ln_post,
                                          self.clip_proj, first_layer_idx=clip_first_tail)
+        # the 2-D mask-proposal branch (side_adapter/side_adaptor_in_veon.py) is
+        # optional: the occupancy path takes only a shape from it.  ``side_adapter``:
+        # True for the SAN defaults or a dict of RegionwiseSideAdapterNetwork.build
+        # arguments.
+        self.side_adapter_network = None
+        if side_adapter:
+            from .semantic_net.side_adapter import RegionwiseSideAdapterNetwork
+            kw = dict(side_adapter) if isinstance(side_adapter, dict) else {}
+            kw.setdefault('attn_heads', clip_heads)
+            self.side_adapter_network = RegionwiseSideAdapterNetwork.build(
+                clip_dim=clip_width, **kw)
+            self.clip_rec_head.sos_token_num = self.side_adapter_network.num_queries
         self.hsa = HighresSideAdaptorNetwork.build(
             dim=hsa_dim, clip_dim=clip_width, mlp_dim=hsa_dim, input_size=input_size,
             fusion_map=hsa_fusion_map, manip_supp_dim=hsa_dim, num_heads=clip_heads,
@@ -119,6 +131,23 @@ class VeonOccupancyPath(nn.Module):
         _, attns, supp = self.hsa(img, feats)
         feats = self.clip_rec_head.update_remaining_clip_feats(feats, None, attns)
         return feats, supp
+
+    def forward_2d(self, images):
+        """The 2-D open-vocabulary segmentation branch (san_in_veon_temporal.py:
+        123-139, 176-186): images (B, N, 3, H, W) -> dict with ``mask_preds``,
+        ``mask_embs``, ``mask_logits``, ``sem_seg_ds``, ``sem_embed_ds``, ``sem_seg``.
+        Needs ``side_adapter=True`` at construction."""
+        if self.side_adapter_network is None:
+            raise RuntimeError('VeonOccupancyPath was built without side_adapter=True')
+        from .semantic_net.side_adapter import semantic_branch_2d
+        img = images.flatten(0, 1)
+        x = F.interpolate(img, scale_factor=0.5, mode='bilinear', align_corners=False)
+        outs, hw = self.clip_trunk(x, last_layer_idx=self.clip_first_tail)
+        feats = {}
+        for i, t in enumerate(outs):
+            ClipRecHead._save(feats, i, t, hw)
+        return semantic_branch_2d(self.side_adapter_network, self.clip_rec_head,
+                                  self.ov_classifier_weight, img, feats)
 
     def _branches(self, images, depth=None):
         """Both encoder branches of one frame -> (CLIP feature dict, supp, depth).
