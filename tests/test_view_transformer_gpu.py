@@ -400,3 +400,32 @@ def test_persistent_output_is_tuned_once_and_identical():
     assert torch.equal(a_copy, want) and torch.equal(b, want)
     # the un-pooled volume is the persistent buffer both times
     assert vt._out_buf is not None and vt._out_buf.shape[1] == feat.shape[2]
+
+
+def test_degenerate_single_voxel_prepare_is_ordered_and_bounded():
+    """Every frustum point of an S2-sized rig (498k points) inside ONE voxel: the
+    rank-counting pass is quadratic in the bin length, so this is its worst case.
+    The order must still be the reference's (ascending point index inside the
+    interval, view_transformer_raw.py:251-270) and the prepare must finish in a
+    bounded time (measured ~10 ms on MI355X; the bound is loose)."""
+    import time
+    vt = build_neck(dict(type='LSSViewTransformerRaw', grid_config=synthetic.GRID_S2,
+                         input_size=(256, 704), out_channels=8, collapse_z=False,
+                         ds_feat=[1, 1, 1])).to(DEV)
+    B, N, D, H, W = 1, 6, vt.D, 16, 44
+    P = B * N * D * H * W
+    coor = torch.empty(B, N, D, H, W, 3, device=DEV)
+    coor[..., 0], coor[..., 1], coor[..., 2] = 3.3, -7.1, 0.4
+    vt.voxel_pooling_prepare_v2(coor)            # warm-up (allocations, module load)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    rb, rd, rf, st, ln = vt.voxel_pooling_prepare_v2(coor)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert st.numel() == 1 and int(ln[0]) == P and int(st[0]) == 0
+    assert torch.equal(rd, torch.arange(P, dtype=rd.dtype, device=DEV))
+    assert int(rb.min()) == int(rb.max())
+    p = torch.arange(P, device=DEV)
+    assert torch.equal(rf.long(), (p // (D * H * W)) * (H * W) + p % (H * W))
+    print('single-voxel prepare of %d points: %.1f ms' % (P, dt * 1e3))
+    assert dt < 2.0, dt

@@ -8,12 +8,16 @@
 //
 //   k_voxel_keys   one lane per frustum point: coordinates (optional output),
 //                  voxel, in-grid test, float32 rank -> key; histogram by atomics
+//                  (one returning atomic per run of equal keys in a wave)
 //   k_scan_*       exclusive scan of the histogram over all voxels (2 kernels:
 //                  per-block sums, then every block adds up the sums before it
 //                  and emits): the dense voxel table vstart (= the row pool
 //                  kernels' index), interval_starts / interval_lengths, counts,
 //                  the 64-voxel tile plan of the slab pool kernels; leaves the
-//                  histogram zeroed for the next call (no memset node)
+//                  histogram zeroed for the next call (no memset node).  (A
+//                  one-pass version -- blocks publishing totals through sc1 words
+//                  and waiting for the blocks before them -- measured 19 us
+//                  against 6 + 5 us for the two launches: cross-XCD round trips.)
 //   k_scatter      points -> their voxel's slot range (slot = the arrival index
 //                  the histogram atomic returned; no second atomic pass)
 //   k_rank_in_bin  deterministic stable order inside every interval
@@ -201,17 +205,18 @@ __global__ __launch_bounds__(kBlock) void k_voxel_keys(
   }
   const int dhw = D * H * W;
   const int i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= dhw) return;
-  const int64_t p = (int64_t)bn * dhw + i;
+  const bool valid = i < dhw;   // no early return: the wave votes below
+  const int ic = valid ? i : dhw - 1;
+  const int64_t p = (int64_t)bn * dhw + ic;
   float c[3];
   if constexpr (FROM == 1) {
     c[0] = coor[p * 3 + 0];
     c[1] = coor[p * 3 + 1];
     c[2] = coor[p * 3 + 2];
   } else {
-    const int w = i % W;
-    const int h = (i / W) % H;
-    const int d = i / (W * H);
+    const int w = ic % W;
+    const int h = (ic / W) % H;
+    const int d = ic / (W * H);
     if constexpr (FROM == 2) {
       // point_coor with this camera's matrices from LDS
       const float* pt = g.post_trans + bn * 3;
@@ -232,8 +237,25 @@ __global__ __launch_bounds__(kBlock) void k_voxel_keys(
   }
   int key = voxel_key(gr, c, bn / N);
   if (key >= n_bins) key = -1;  // cannot happen for consistent grids; be safe
-  keys[p] = key;
-  if (key >= 0) slots[p] = atomicAdd(hist + key, 1);
+  if (!valid) key = -2;
+  // Neighbouring pixels of one image row mostly fall into the same voxel: a run of
+  // consecutive lanes with one key takes ONE returning atomic (by its first lane,
+  // for the whole run) instead of one per point.
+  const int lane = threadIdx.x & 63;
+  const int prev = __shfl_up(key, 1);
+  const bool head = lane == 0 || prev != key;
+  const unsigned long long hm = __ballot(head);
+  const unsigned long long upto = (2ull << lane) - 1ull;   // lanes 0..lane
+  const int head_lane = 63 - __clzll((long long)(hm & upto));
+  const unsigned long long above = hm & ~upto;
+  const int next = above ? __ffsll((long long)above) - 1 : 64;
+  int base = 0;
+  if (head && key >= 0) base = atomicAdd(hist + key, next - head_lane);
+  base = __shfl(base, head_lane);
+  if (valid) {
+    keys[p] = key;
+    if (key >= 0) slots[p] = base + (lane - head_lane);
+  }
 }
 
 // ---- exclusive scan over the histogram (count and non-empty flag) ----------
@@ -375,20 +397,45 @@ __global__ __launch_bounds__(kBlock) void k_scatter(
 }
 
 // stable order inside each interval: final slot = start + #points of the
-// interval with a smaller index.  One lane per kept point.
+// interval with a smaller index.  One lane per kept point; the slot range the
+// block's 256 points' voxels cover is staged in LDS once (what does not fit -- a
+// voxel with thousands of points -- is read from global memory).  Quadratic in the
+// voxel's length: 498k points in ONE voxel take ~10 ms (tests/
+// test_view_transformer_gpu.py::test_degenerate_single_voxel...).
+constexpr int kRankSpan = 3072;
+
 __global__ __launch_bounds__(kBlock) void k_rank_in_bin(
     const int* __restrict__ keys, const int* __restrict__ tmp_point,
     const int* __restrict__ counts, const int* __restrict__ bin_start, int D, int HW,
     int* __restrict__ ranks_bev,
     int* __restrict__ ranks_depth, int* __restrict__ ranks_feat) {
-  const int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (q >= counts[0]) return;
-  const int p = tmp_point[q];
-  const int key = keys[p];
-  const int start = bin_start[key];
-  const int len = bin_start[key + 1] - start;
+  __shared__ int sp[kRankSpan];
+  __shared__ int lo_s, hi_s;
+  const int kept = counts[0];
+  const int64_t q0 = (int64_t)blockIdx.x * kBlock;
+  if (q0 >= kept) return;   // block-uniform
+  const int64_t q = q0 + threadIdx.x;
+  const bool valid = q < kept;
+  int p = 0, key = 0, start = 0, len = 0;
+  if (valid) {
+    p = tmp_point[q];
+    key = keys[p];
+    start = bin_start[key];
+    len = bin_start[key + 1] - start;
+  }
+  if (threadIdx.x == 0) lo_s = start;
+  if (valid && (q == kept - 1 || threadIdx.x == kBlock - 1)) hi_s = start + len;
+  __syncthreads();
+  const int lo = lo_s;
+  const int hi = min(hi_s, lo + kRankSpan);
+  for (int i = threadIdx.x; i < hi - lo; i += kBlock) sp[i] = tmp_point[lo + i];
+  __syncthreads();
+  if (!valid) return;
+  const int end = start + len;
   int rank = 0;
-  for (int i = 0; i < len; ++i) rank += tmp_point[start + i] < p;
+  const int s_end = min(end, hi) - lo;
+  for (int i = start - lo; i < s_end; ++i) rank += sp[i] < p;
+  for (int i = max(start, hi); i < end; ++i) rank += tmp_point[i] < p;
   const int slot = start + rank;
   ranks_bev[slot] = key;
   ranks_depth[slot] = p;
@@ -517,6 +564,7 @@ static int prepare_impl(int B, int N, int D, int H, int W, const float* coor,
   }
   Geometry g{xs, ys, ds, post_rots_inv, post_trans, combine, trans, bda};
   CameraRaw cr{sensor2ego, cam2imgs, post_rots};
+  const int n_scan_blocks = (int)((n_bins + kScanBlock - 1) / kScanBlock);
   if (!hist_is_zero &&
       hipMemsetAsync(w.hist, 0, (size_t)n_bins * 4, s) != hipSuccess)
     return VEON_ERR_LAUNCH;
@@ -533,10 +581,9 @@ static int prepare_impl(int B, int N, int D, int H, int W, const float* coor,
   else
     hipLaunchKernelGGL(k_voxel_keys<0>, kgrid, dim3(kBlock), 0, s, g, cr, coor, gr, N,
                        D, H, W, n_bins, w.keys, w.slots, w.hist);
-  const int n_scan_blocks = (int)((n_bins + kScanBlock - 1) / kScanBlock);
+  const int64_t tiles_per_batch = voxels_per_batch / kTileV;
   hipLaunchKernelGGL(k_scan_reduce, dim3(n_scan_blocks), dim3(kBlock), 0, s,
                      w.hist, n_bins, w.block_sums);
-  const int64_t tiles_per_batch = voxels_per_batch / kTileV;
   hipLaunchKernelGGL(k_scan_emit, dim3(n_scan_blocks), dim3(kBlock), 0, s, w.hist,
                      n_bins, w.block_sums, table, interval_starts, interval_lengths,
                      reinterpret_cast<int4*>(plan), voxels_per_batch, tiles_per_batch,

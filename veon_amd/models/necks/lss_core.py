@@ -159,13 +159,31 @@ class LSSCore(_Base):
             bev_feat = torch.cat(bev_feat.unbind(dim=2), 1)
         return bev_feat
 
+    def _rows_beside_prepare(self, feat_l, depth):
+        """Inside a hipGraph capture the feature layout change (NCHW -> pixel rows)
+        is put on a forked stream, so the graph runs it BESIDE the prepare kernels
+        it does not depend on; eager calls keep one stream (the fork would cost more
+        host time than the 9 us kernel).  -> (rows, join) ; call join() before the
+        pool launch."""
+        if not (feat_l.is_cuda and torch.cuda.is_current_stream_capturing()):
+            return feat_l, lambda: None
+        cur = torch.cuda.current_stream(feat_l.device)
+        side = self.__dict__.get('_fork_stream')
+        if side is None or side.device != feat_l.device:
+            side = self.__dict__['_fork_stream'] = torch.cuda.Stream(feat_l.device)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            rows = _bp._inference_feat(feat_l, depth)
+        return rows, lambda: cur.wait_stream(side)
+
     def _lift_sync_free(self, input, depth, feat):
         sensor2ego, _, cam2imgs, post_rots, post_trans, bda = input[1:7]
+        feat_l, join = self._rows_beside_prepare(feat.permute(0, 1, 3, 4, 2), depth)
         pre = _prep._HIP_PREPARE.prepare_cameras(
             self.frustum, sensor2ego, cam2imgs, post_rots, post_trans, bda,
             self.grid_lower_bound, self.grid_interval, self.grid_size)
+        join()
         shape = self._bev_feat_shape(depth.shape[0], feat.shape[2])
-        feat_l = feat.permute(0, 1, 3, 4, 2)
         out = None
         if self.persistent_output:
             out = self._persistent_volume(
@@ -192,9 +210,11 @@ class LSSCore(_Base):
                 out_volume=out_volume)
         sensor2ego, _, cam2imgs, post_rots, post_trans, bda = input[1:7]
         if self.sync_free:
+            feat, join = self._rows_beside_prepare(feat, depth)
             pre = _prep._HIP_PREPARE.prepare_cameras(
                 self.frustum, sensor2ego, cam2imgs, post_rots, post_trans, bda,
                 self.grid_lower_bound, self.grid_interval, self.grid_size)
+            join()
             return _bp.bev_pool_v2_maxpool(
                 depth, feat, pre.ranks_depth, pre.ranks_feat, pre.ranks_bev,
                 shape, pre.interval_starts, pre.interval_lengths, ds,
