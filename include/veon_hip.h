@@ -362,6 +362,13 @@ int veon_two_hot_depth(int BN, int H, int W, int ds, int D, float lo, float step
  * veon_vit_gemm (-1 = automatic, 0 = small-tile kernel, 1..6 = ring-kernel tiles) */
 void veon_gemm_ring_set(int config);
 int veon_vit_cast_bf16(const float *in, void *out_bf16, int64_t n, void *stream);
+/* Patch embedding (dinov2_layers/patch_embed.py: Conv2d(kernel = stride = patch)) as a
+ * GEMM operand: img fp32 (B,C,H,W) -> bf16 rows [B*(skip + h*w)][kpad], row element
+ * c*patch*patch + i*patch + j (the conv weight's order), zero beyond C*patch*patch,
+ * ``skip`` zero rows in front of every image (class-token slot).  A remainder of H/W
+ * modulo patch is not read (as the convolution). */
+int veon_vit_patchify(const float *img, void *out_bf16, int B, int C, int H, int W,
+                      int patch, int skip, int kpad, void *stream);
 int veon_vit_layernorm(const float *x, const float *gamma, const float *beta,
                        void *out_bf16, int T, int d, float eps, void *stream);
 int veon_vit_gemm(const void *a_bf16, const void *w_bf16, const float *bias,
@@ -466,6 +473,20 @@ int veon_image_unpack(const void *padded, void *nchw, int nchw_is_bf16, int B,
 int veon_image_resize_bilinear(const void *in_padded, void *out_padded, int B,
                                int C, int Yi, int Xi, int Yo, int Xo,
                                void *stream);
+/* ViT token rows -> padded image, with the pixel shuffle of a ConvTranspose2d(k = s,
+ * stride = s) folded in (DPTHead.resize_layers[0:2], depth_anything/dpt.py:55-72:
+ * the transposed convolution itself is a GEMM over the tokens whose output row holds
+ * the s*s pixels [i][j][C] of one token).  rows: bf16 [B*tokens_per_image][row_elems]
+ * (row_elems >= s*s*C); the first ``skip`` rows of every image (class token) are
+ * passed over; out: padded image (B, C, s*h, s*w), interior written.  C % 8 == 0. */
+int veon_tokens_to_image(const void *rows, int64_t row_elems, int tokens_per_image,
+                         int skip, int h, int w, int s, int C, void *out_padded, int B,
+                         void *stream);
+/* out(y,x) = in(step*y, step*x) between padded images (B,C,Yi,Xi) ->
+ * (B,C,ceil(Yi/step),ceil(Xi/step)): a stride-``step`` 3x3 pad-1 convolution
+ * (DPTHead.resize_layers[3]) is veon_conv2d_k3_bf16 followed by this. */
+int veon_image_subsample(const void *in_padded, void *out_padded, int B, int C, int Yi,
+                         int Xi, int step, void *stream);
 /* out (B,Y,X) fp32 = act(1x1 conv C -> 1 of a padded image + bias); C in {32, 64};
  * act 0 none / 1 ReLU / 2 sigmoid (the tail of DPTHead.output_conv2, dpt.py). */
 int veon_image_dot(const void *in_padded, const float *w, float bias, float *out,

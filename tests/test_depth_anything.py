@@ -157,3 +157,71 @@ def test_dpt_head_bf16_mfma_convs_match_autocast():
     err_hip = ((got - ref32).norm() / ref32.norm()).item()
     err_amp = ((want - ref32).norm() / ref32.norm()).item()
     assert err_hip < max(2.0 * err_amp, 2e-2), (err_hip, err_amp)
+
+
+@pytest.mark.gpu
+def test_native_depth_forward_tokens_to_depth():
+    """forward() with head_dtype = bf16: LayerNormed bf16 token rows of the four taps
+    -> projection / transposed-conv GEMMs -> pixel-shuffle pack -> 3x3 convs (stride
+    2 as stride 1 + subsample) -> fusion blocks, no PyTorch op in the head.  Against
+    the fp32 head on the same encoder output, and against PyTorch's bf16 autocast of
+    the head (the error budget)."""
+    import torch
+    from veon_amd import _lib
+    from veon_amd.models import build_neck
+    from veon_amd.models.depth_anything import dpt
+    torch.manual_seed(0)
+    m = build_neck(dict(type='DepthAnythingV2Adaptor', max_depth=80.0, use_lora=True,
+                        lora_r=4, encoder='vits', features=128,
+                        out_channels=[48, 96, 192, 384])).to('cuda:0').eval()
+    with torch.no_grad():   # default-initialised biases are zero: make every term count
+        for p_ in m.depth_head.parameters():
+            if p_.dim() == 1:
+                p_.normal_(0, 0.05)
+    x = torch.randn(2, 3, 70, 98, device='cuda:0')     # 5 x 7 patches (odd: s2 conv edge)
+    with torch.no_grad():
+        m.head_dtype = torch.bfloat16
+        before = dict(_lib.CALLS)
+        got = m(x)['metric_depth']
+        ran = {k: _lib.CALLS.get(k, 0) - before.get(k, 0)
+               for k in ('veon_tokens_to_image', 'veon_image_subsample')}
+        ok = dpt.DPTHead.hip_front_ok
+        dpt.DPTHead.hip_front_ok = lambda self, rows: False
+        okc = dpt._hip_convs_ok
+        dpt._hip_convs_ok = lambda *a, **k: False          # PyTorch autocast path
+        try:
+            amp = m(x)['metric_depth']
+        finally:
+            dpt.DPTHead.hip_front_ok, dpt._hip_convs_ok = ok, okc
+        m.head_dtype = None
+        ref32 = m(x)['metric_depth']
+    assert ran == {'veon_tokens_to_image': 4, 'veon_image_subsample': 1}, ran
+    assert got.shape == ref32.shape == (2, 70, 98)
+    err_hip = ((got - ref32).norm() / ref32.norm()).item()
+    err_amp = ((amp - ref32).norm() / ref32.norm()).item()
+    assert err_hip < max(2.0 * err_amp, 2e-2), (err_hip, err_amp)
+
+
+@pytest.mark.gpu
+def test_intermediate_rows_match_reference_taps():
+    """The native hand-over of the encoder (patch GEMM + bf16 LayerNormed tap rows)
+    against the reference's own tap outputs (golden: get_intermediate_layers with
+    norm=True): relative L2 error <= 1e-2 (bf16 operands incl. the image patches)."""
+    g = load_golden('dinov2_tiny')
+    enc, _ = _build(g)
+    enc = enc.to('cuda:0')
+    x = torch.from_numpy(g['x']).to('cuda:0')
+    taps = [int(t) for t in g['taps']]
+    with torch.no_grad():
+        rows = enc.intermediate_rows(x, taps)
+        tok = enc._native_tokens(x).view(x.shape[0], -1, enc.embed_dim)
+        ref_tok = enc.prepare_tokens_with_masks(x)
+    assert rows is not None and len(rows) == len(taps)
+    assert ((tok - ref_tok).norm() / ref_tok.norm()).item() < 5e-3
+    B = x.shape[0]
+    for i, r in enumerate(rows):
+        assert r.dtype == torch.bfloat16
+        r = r.float().view(B, -1, enc.embed_dim).cpu().numpy()
+        patch, cls = g['tap_patch'][i], g['tap_cls'][i]
+        assert np.linalg.norm(r[:, 1:] - patch) / np.linalg.norm(patch) < 1e-2
+        assert np.linalg.norm(r[:, 0] - cls) / np.linalg.norm(cls) < 1e-2

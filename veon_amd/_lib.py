@@ -65,6 +65,7 @@ _SIGNATURES = {
     'veon_gemm_ring_set': (None, [_ci]),
     'veon_vit_cast_bf16': (_ci, [_vp, _vp, _i64, _vp]),
     'veon_vit_layernorm': (_ci, [_vp, _vp, _vp, _vp, _ci, _ci, _cf, _vp]),
+    'veon_vit_patchify': (_ci, [_vp, _vp] + [_ci] * 7 + [_vp]),
     'veon_vit_gemm': (_ci, [_vp] * 6 + [_ci] * 4 + [_vp]),
     'veon_vit_attention': (_ci, [_vp, _vp, _i64, _i64, _vp, _ci, _ci, _ci, _ci, _vp]),
     'veon_vit_block_workspace_bytes': (_i64, [_ci] * 4),
@@ -74,6 +75,8 @@ _SIGNATURES = {
     'veon_conv2d_k3_bf16': (_ci, [_vp] * 6 + [_ci] * 6 + [_vp]),
     'veon_image_resize_bilinear': (_ci, [_vp, _vp] + [_ci] * 6 + [_vp]),
     'veon_image_dot': (_ci, [_vp, _vp, _cf, _vp] + [_ci] * 5 + [_vp]),
+    'veon_tokens_to_image': (_ci, [_vp, _i64] + [_ci] * 6 + [_vp, _ci, _vp]),
+    'veon_image_subsample': (_ci, [_vp, _vp] + [_ci] * 5 + [_vp]),
     'veon_image_pack_bf16': (_ci, [_vp, _ci, _vp] + [_ci] * 4 + [_vp]),
     'veon_image_unpack': (_ci, [_vp, _vp, _ci] + [_ci] * 4 + [_vp]),
     'veon_alloc_contiguous': (_ci, [_vp, _i64]),

@@ -321,6 +321,38 @@ def resize_bilinear(img, size, out=None):
     return out
 
 
+def tokens_to_image(rows, tokens_per_image, skip, h, w, s, C, out):
+    """bf16 token rows [B*tokens_per_image, >= s*s*C] (the GEMM output of a
+    ConvTranspose2d(k = s, stride = s) applied to the tokens; s = 1: plain tokens)
+    -> interior of the PaddedImage ``out`` (B, C, s*h, s*w); the first ``skip`` rows
+    of every image (class token) are passed over."""
+    dev = _lib.require_device(rows, out.storage)
+    B = out.shape[0]
+    assert rows.dtype == torch.bfloat16 and rows.is_contiguous() and rows.dim() == 2
+    assert out.shape == (B, C, s * h, s * w) and rows.shape[0] == B * tokens_per_image
+    with _lib.on_device(dev):
+        st = _lib.lib().veon_tokens_to_image(
+            _lib.ptr(rows), rows.shape[1], tokens_per_image, skip, h, w, s, C,
+            _lib.ptr(out.rows), B, _lib.stream_ptr(dev))
+    _lib.check(st, 'veon_tokens_to_image')
+    return out
+
+
+def image_subsample(img, step, out=None):
+    """out(y,x) = img(step*y, step*x) -> PaddedImage (B, C, ceil(Y/step), ceil(X/step))."""
+    dev = _lib.require_device(img.storage)
+    B, C, Y, X = img.shape
+    Yo, Xo = (Y + step - 1) // step, (X + step - 1) // step
+    if out is None:
+        out = PaddedImage(B, C, Yo, Xo, dev)
+    assert out.shape == (B, C, Yo, Xo)
+    with _lib.on_device(dev):
+        st = _lib.lib().veon_image_subsample(_lib.ptr(img.rows), _lib.ptr(out.rows), B, C,
+                                             Y, X, step, _lib.stream_ptr(dev))
+    _lib.check(st, 'veon_image_subsample')
+    return out
+
+
 def image_dot(img, w, bias, act='none'):
     """1x1 conv C -> 1 (+activation) of a PaddedImage -> (B,1,H,W) fp32.
     w fp32 [C], act in none / relu / sigmoid."""

@@ -331,6 +331,54 @@ __global__ __launch_bounds__(256) void k_resize_bilinear_padded(
   *reinterpret_cast<uint4*>(op) = make_uint4(o[0], o[1], o[2], o[3]);
 }
 
+// Token rows of a ViT -> padded image, with the pixel shuffle of a stride == kernel
+// transposed convolution folded in: the GEMM that applies ConvTranspose2d(k = s,
+// stride = s) to the tokens leaves, per token (y, x), the s*s output pixels side by
+// side in one row ([i][j][C]); output pixel (s*y + i, s*x + j) is columns
+// (i*s + j)*C .. +C of that row.  ``skip`` leading rows per image (the class token)
+// are passed over.  s == 1 is the plain tokens -> image pack.  One lane = 8 channels.
+__global__ __launch_bounds__(256) void k_tokens_to_image(
+    const bf16_t* __restrict__ src, int64_t row_elems, int T, int skip, int h, int w,
+    int s, int C, bf16_t* __restrict__ out, int B) {
+  const int c8 = C / 8;
+  const int Yo = h * s, Xo = w * s;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t total = (int64_t)B * Yo * Xo * c8;
+  if (idx >= total) return;
+  const int cc = (int)(idx % c8) * 8;
+  int64_t p = idx / c8;
+  const int xo = (int)(p % Xo);
+  p /= Xo;
+  const int yo = (int)(p % Yo);
+  const int b = (int)(p / Yo);
+  const int y = yo / s, i = yo - y * s, x = xo / s, j = xo - x * s;
+  const bf16_t* ip = src + ((int64_t)b * T + skip + (int64_t)y * w + x) * row_elems +
+                     (int64_t)(i * s + j) * C + cc;
+  bf16_t* op = out + (((int64_t)b * (Yo + 2) + yo + 1) * (Xo + 2) + xo + 1) * C + cc;
+  *reinterpret_cast<uint4*>(op) = *reinterpret_cast<const uint4*>(ip);
+}
+
+// out(y, x) = in(step*y, step*x) between padded images: a stride-``step`` 3x3
+// convolution is the stride-1 one sampled at every ``step``-th pixel.
+__global__ __launch_bounds__(256) void k_image_subsample(
+    const bf16_t* __restrict__ in, bf16_t* __restrict__ out, int B, int C, int Yi,
+    int Xi, int Yo, int Xo, int step) {
+  const int c8 = C / 8;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t total = (int64_t)B * Yo * Xo * c8;
+  if (idx >= total) return;
+  const int cc = (int)(idx % c8) * 8;
+  int64_t p = idx / c8;
+  const int xo = (int)(p % Xo);
+  p /= Xo;
+  const int yo = (int)(p % Yo);
+  const int b = (int)(p / Yo);
+  const bf16_t* ip =
+      in + (((int64_t)b * (Yi + 2) + yo * step + 1) * (Xi + 2) + xo * step + 1) * C + cc;
+  bf16_t* op = out + (((int64_t)b * (Yo + 2) + yo + 1) * (Xo + 2) + xo + 1) * C + cc;
+  *reinterpret_cast<uint4*>(op) = *reinterpret_cast<const uint4*>(ip);
+}
+
 // out[b][y][x] = act(sum_c in[b][y][x][c] * w[c] + bias): the last 1x1 conv of a
 // dense-prediction head (C -> 1) with its activation, straight from the padded
 // channels-last image to a planar fp32 map.  One lane per pixel; a wave reads a
@@ -627,6 +675,39 @@ int veon_image_resize_bilinear(const void* in_padded, void* out_padded, int B,
                      static_cast<hipStream_t>(stream),
                      static_cast<const bf16_t*>(in_padded),
                      static_cast<bf16_t*>(out_padded), B, C, Yi, Xi, Yo, Xo, sy, sx);
+  return launch_status();
+}
+
+int veon_tokens_to_image(const void* rows, int64_t row_elems, int tokens_per_image,
+                         int skip, int h, int w, int s, int C, void* out_padded, int B,
+                         void* stream) {
+  if (B <= 0 || h <= 0 || w <= 0 || s <= 0 || C <= 0 || C % 8 != 0 || skip < 0 ||
+      !rows || !out_padded || !al16(rows) || !al16(out_padded) || row_elems % 8 != 0 ||
+      row_elems < (int64_t)s * s * C || tokens_per_image < skip + h * w)
+    return VEON_ERR_BAD_ARG;
+  const int64_t total = (int64_t)B * h * s * w * s * (C / 8);
+  const int64_t blocks = (total + 255) / 256;
+  if (blocks > 0x7fffffffLL) return VEON_ERR_BAD_ARG;
+  hipLaunchKernelGGL(k_tokens_to_image, dim3((unsigned)blocks), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), static_cast<const bf16_t*>(rows),
+                     row_elems, tokens_per_image, skip, h, w, s, C,
+                     static_cast<bf16_t*>(out_padded), B);
+  return launch_status();
+}
+
+int veon_image_subsample(const void* in_padded, void* out_padded, int B, int C, int Yi,
+                         int Xi, int step, void* stream) {
+  if (B <= 0 || C <= 0 || C % 8 != 0 || Yi <= 0 || Xi <= 0 || step <= 0 || !in_padded ||
+      !out_padded || !al16(in_padded) || !al16(out_padded))
+    return VEON_ERR_BAD_ARG;
+  const int Yo = (Yi + step - 1) / step, Xo = (Xi + step - 1) / step;
+  const int64_t total = (int64_t)B * Yo * Xo * (C / 8);
+  const int64_t blocks = (total + 255) / 256;
+  if (blocks > 0x7fffffffLL) return VEON_ERR_BAD_ARG;
+  hipLaunchKernelGGL(k_image_subsample, dim3((unsigned)blocks), dim3(256), 0,
+                     static_cast<hipStream_t>(stream),
+                     static_cast<const bf16_t*>(in_padded),
+                     static_cast<bf16_t*>(out_padded), B, C, Yi, Xi, Yo, Xo, step);
   return launch_status();
 }
 

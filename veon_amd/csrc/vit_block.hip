@@ -775,6 +775,32 @@ __global__ __launch_bounds__(256, 2) void k_attention(
   }
 }
 
+// Patch embedding as a GEMM operand: the non-overlapping p x p patches of an fp32
+// NCHW image as bf16 rows [b][skip + y*w + x][c*p*p + i*p + j] (nn.Conv2d's weight
+// order), K padded with zeros to ``kpad``, ``skip`` all-zero rows in front of every
+// image (the class token's slot: the GEMM then adds only its bias there).  One lane
+// = one row element; consecutive lanes walk a patch row (j), so image reads are
+// contiguous runs of p floats.
+__global__ __launch_bounds__(256) void k_patchify_bf16(
+    const float* __restrict__ img, bf16_t* __restrict__ out, int B, int C, int H, int W,
+    int p, int h, int w, int skip, int kpad) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int T = skip + h * w;
+  if (idx >= (int64_t)B * T * kpad) return;
+  const int col = (int)(idx % kpad);
+  const int64_t row = idx / kpad;
+  const int t = (int)(row % T) - skip;
+  const int b = (int)(row / T);
+  float v = 0.f;
+  if (t >= 0 && col < C * p * p) {
+    const int c = col / (p * p), r = col - c * p * p;
+    const int i = r / p, j = r - i * p;
+    const int y = t / w, x = t - y * w;
+    v = img[(((int64_t)b * C + c) * H + y * p + i) * W + x * p + j];
+  }
+  out[idx] = f2bf(v);
+}
+
 // fp32 -> bf16 cast (weights / activations entering the bf16 path)
 __global__ __launch_bounds__(256) void k_cast_bf16(const float* __restrict__ in,
                                                    bf16_t* __restrict__ out,
@@ -927,6 +953,21 @@ int veon_vit_cast_bf16(const float* in, void* out, int64_t n, void* stream) {
   hipLaunchKernelGGL(k_cast_bf16, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), in,
                      static_cast<bf16_t*>(out), n);
+  return launch_status();
+}
+
+int veon_vit_patchify(const float* img, void* out_bf16, int B, int C, int H, int W,
+                      int patch, int skip, int kpad, void* stream) {
+  if (B <= 0 || C <= 0 || patch <= 0 || H < patch || W < patch || skip < 0 ||
+      kpad < C * patch * patch || !img || !out_bf16)
+    return VEON_ERR_BAD_ARG;
+  const int h = H / patch, w = W / patch;
+  const int64_t n = (int64_t)B * (skip + h * w) * kpad;
+  const int64_t blocks = (n + 255) / 256;
+  if (blocks > 0x7fffffffLL) return VEON_ERR_BAD_ARG;
+  hipLaunchKernelGGL(k_patchify_bf16, dim3((unsigned)blocks), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), img,
+                     static_cast<bf16_t*>(out_bf16), B, C, H, W, patch, h, w, skip, kpad);
   return launch_status();
 }
 

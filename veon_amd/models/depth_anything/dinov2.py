@@ -261,6 +261,33 @@ class DinoVisionTransformer(nn.Module):
         x = torch.cat((self.cls_token.expand(B, -1, -1), x), dim=1)
         return x + self.interpolate_pos_encoding(x, w, h)
 
+    def _native_tokens(self, x):
+        """``prepare_tokens_with_masks`` at inference as: position rows copied into
+        the fp32 stream, patches gathered as bf16 GEMM rows (class-token slots zero),
+        one MFMA GEMM accumulating conv-weight x patch + bias onto the stream.  Row 0
+        of the copied block holds cls + pos[0] - bias, so the GEMM's bias lands it on
+        cls + pos[0].  -> fp32 [B*T, d]."""
+        B, _, H, W = x.shape
+        p, d = self.patch_size, self.embed_dim
+        key = ('tok', H, W, x.device)
+        if key not in self._pos_cache:
+            proj = self.patch_embed.proj
+            k = proj.in_channels * p * p
+            kpad = (k + 63) // 64 * 64
+            wp = torch.zeros(d, kpad, device=x.device)
+            wp[:, :k] = proj.weight.detach().float().view(d, k)
+            bias = (proj.bias.detach().float().contiguous() if proj.bias is not None
+                    else torch.zeros(d, device=x.device))
+            T = 1 + (H // p) * (W // p)
+            probe = torch.empty(1, T, d, device=x.device)
+            base = self.interpolate_pos_encoding(probe, H, W).float()[0].clone()
+            base[0] += self.cls_token.detach().float().view(d) - bias
+            self._pos_cache[key] = (vit_ops.to_bf16(wp), bias, base.contiguous(), kpad)
+        wp, bias, base, kpad = self._pos_cache[key]
+        s = base.unsqueeze(0).expand(B, -1, -1).reshape(B * base.shape[0], d)
+        a = vit_ops.patchify(x, p, 1, kpad)
+        return vit_ops.linear_residual_(s, a, wp, bias)
+
     # ------------------------------------------------------------- blocks
     def invalidate_hip_cache(self):
         """Call after changing weights when the inference caches are in use."""
@@ -309,6 +336,27 @@ class DinoVisionTransformer(nn.Module):
             if i in taps:
                 outs.append(x)
         return outs, x
+
+    def intermediate_rows(self, x, taps):
+        """Native twin of ``get_intermediate_layers(x, taps, norm=True)``: the final
+        LayerNorm of every tapped block output, as bf16 ROWS [B*T, d] (class token
+        first in every image) straight off the fp32 residual stream -- no clone of
+        the stream, no fp32 normalised copy.  None when the MFMA path is off."""
+        if not self._use_hip(x):
+            return None
+        if self._hip_weights is None:
+            self._hip_weights = [_HipBlockWeights(b) for b in self.blocks]
+        s = self._native_tokens(x)
+        B, d = x.shape[0], self.embed_dim
+        T = s.shape[0] // B
+        ws = vit_ops.block_workspace(B, T, d, self._hip_weights[0].packed.mlp_dim, x.device)
+        nw, nb = self.norm.weight.detach().float(), self.norm.bias.detach().float()
+        outs = []
+        for i, w in enumerate(self._hip_weights):
+            vit_ops.block_forward_(s, w.packed, B, T, ws)
+            if i in taps:
+                outs.append(vit_ops.layernorm(s, nw, nb, self.norm.eps))
+        return outs
 
     def forward_features(self, x, masks=None):
         x = self.prepare_tokens_with_masks(x, masks)

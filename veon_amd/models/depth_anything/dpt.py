@@ -158,7 +158,7 @@ def _make_scratch(in_shape, out_shape):
 
 
 class DPTHead(NativeCacheMixin, nn.Module):
-    _native_cache = ('_hip_convs', '_hip_in', '_hip_tail')
+    _native_cache = ('_hip_convs', '_hip_in', '_hip_tail', '_hip_front_w')
 
     def __init__(self, in_channels, features=256, use_bn=False,
                  out_channels=[256, 512, 1024, 1024], use_clstoken=False):
@@ -213,10 +213,104 @@ class DPTHead(NativeCacheMixin, nn.Module):
                             mode='bilinear', align_corners=True)
         return s.output_conv2(out)
 
+    # ---- native front: tokens -> the four pyramid levels, no PyTorch op ----------
+    def hip_front_ok(self, rows):
+        """bf16 inference from normalised token ROWS (dinov2 ``intermediate_rows``):
+        the four 1x1 projections and the two transposed convolutions are GEMMs over
+        the token rows, the stride-2 and ``layerN_rn`` 3x3 convolutions run on the
+        MFMA conv kernel; see ``_hip_front``."""
+        s = self.scratch
+        rl = self.resize_layers
+        return (not self.use_clstoken and rows.is_cuda and rows.dtype == torch.bfloat16
+                and not torch.is_grad_enabled() and rows.shape[-1] % 64 == 0
+                and isinstance(rl[0], nn.ConvTranspose2d) and rl[0].kernel_size == (4, 4)
+                and isinstance(rl[1], nn.ConvTranspose2d) and rl[1].kernel_size == (2, 2)
+                and isinstance(rl[2], nn.Identity) and isinstance(rl[3], nn.Conv2d)
+                and rl[3].kernel_size == (3, 3) and rl[3].stride == (2, 2)
+                and s.layer1_rn.out_channels % 64 == 0
+                and all(getattr(s, 'refinenet%d' % i).hip_ok(rows) for i in (1, 2, 3, 4))
+                and _hip_convs_ok(rows, s.output_conv1, s.output_conv2[0]))
+
+    def _front_weights(self, dev):
+        if '_hip_front_w' in self.__dict__:
+            return self.__dict__['_hip_front_w']
+        s = self.scratch
+        levels = []
+        for i in range(4):
+            pj = self.projects[i]
+            oc, d = pj.out_channels, pj.in_channels
+            ocp = (oc + 63) // 64 * 64
+            w1 = torch.zeros(ocp, d, device=dev)
+            b1 = torch.zeros(ocp, device=dev)
+            w1[:oc] = pj.weight.detach().float().view(oc, d)
+            b1[:oc] = pj.bias.detach().float()
+            lv = {'ocp': ocp, 'w1': w1.to(torch.bfloat16).contiguous(), 'b1': b1}
+            rl = self.resize_layers[i]
+            if isinstance(rl, nn.ConvTranspose2d):
+                # out[(s*y+i, s*x+j), co] = b[co] + sum_c in[(y,x), c] W[c, co, i, j]
+                k = rl.kernel_size[0]
+                w2 = torch.zeros(k, k, ocp, ocp, device=dev)
+                w2[:, :, :oc, :oc] = rl.weight.detach().float().permute(2, 3, 1, 0)
+                b2 = torch.zeros(k, k, ocp, device=dev)
+                b2[:, :, :oc] = rl.bias.detach().float()
+                lv.update(s=k, w2=w2.view(k * k * ocp, ocp).to(torch.bfloat16).contiguous(),
+                          b2=b2.view(-1).contiguous())
+            elif isinstance(rl, nn.Conv2d):
+                wc = torch.zeros(ocp, ocp, 3, 3, device=dev)
+                wc[:oc, :oc] = rl.weight.detach().float()
+                bc = torch.zeros(ocp, device=dev)
+                bc[:oc] = rl.bias.detach().float()
+                lv.update(s=1, wc=conv3d_ops.pack_weight2d(wc), bc=bc)
+            else:
+                lv['s'] = 1
+            rn = getattr(s, 'layer%d_rn' % (i + 1))
+            wr = torch.zeros(rn.out_channels, ocp, 3, 3, device=dev)
+            wr[:, :oc] = rn.weight.detach().float()
+            lv['wr'] = conv3d_ops.pack_weight2d(wr)
+            lv['br'] = (rn.bias.detach().float().contiguous() if rn.bias is not None
+                        else None)
+            levels.append(lv)
+        self.__dict__['_hip_front_w'] = levels
+        return levels
+
+    def _hip_front(self, taps, B, T, patch_h, patch_w):
+        """taps: four bf16 [B*T, d] matrices of normalised tokens (class token first
+        in every image).  -> the four ``layerN_rn`` outputs as PaddedImages."""
+        dev = taps[0].device
+        ins = self.__dict__.setdefault('_hip_in', {})
+
+        def image(tag, C, Y, X):
+            key = (tag, B, C, Y, X)
+            if key not in ins:
+                ins[key] = conv3d_ops.PaddedImage(B, C, Y, X, dev)
+            return ins[key]
+        outs = []
+        for i, (rows, lv) in enumerate(zip(taps, self._front_weights(dev))):
+            ocp, sc = lv['ocp'], lv['s']
+            x = vit_ops.linear(rows, lv['w1'], lv['b1'], vit_ops.EPI_BF16)
+            if 'w2' in lv:
+                x = vit_ops.linear(x, lv['w2'], lv['b2'], vit_ops.EPI_BF16)
+            img = conv3d_ops.tokens_to_image(x, T, T - patch_h * patch_w, patch_h, patch_w,
+                                             sc, ocp, image(('lvl', i), ocp, sc * patch_h,
+                                                            sc * patch_w))
+            if 'wc' in lv:   # 3x3 stride 2 = the stride-1 conv at every second pixel
+                full = conv3d_ops.conv2d_k3(img, lv['wc'], None, lv['bc'],
+                                            out=image(('s2', i), ocp, patch_h, patch_w))
+                img = conv3d_ops.image_subsample(
+                    full, 2, out=image(('sub', i), ocp, (patch_h + 1) // 2,
+                                       (patch_w + 1) // 2))
+            Y, X = img.shape[2:]
+            outs.append(conv3d_ops.conv2d_k3(img, lv['wr'], None, lv['br'],
+                                             out=image(('rn', i), lv['wr'].shape[0], Y, X)))
+        return outs
+
+    def hip_forward(self, taps, B, T, patch_h, patch_w):
+        i1, i2, i3, i4 = self._hip_front(taps, B, T, patch_h, patch_w)
+        return self._hip_refine_images(i1, i2, i3, i4, patch_h, patch_w)
+
     def _hip_refine(self, l1, l2, l3, l4, patch_h, patch_w):
         """Fusion blocks + output convs entirely in the padded channels-last
         bf16 layout of the MFMA conv kernel: four packs in, one unpack out."""
-        s = self.scratch
         ins = self.__dict__.setdefault('_hip_in', {})
 
         def packed(tag, t):
@@ -225,9 +319,14 @@ class DPTHead(NativeCacheMixin, nn.Module):
                 ins[key] = conv3d_ops.PaddedImage(*t.shape, t.device)
             return conv3d_ops.pack_image(t, out=ins[key])
         i1, i2, i3, i4 = (packed(k, t) for k, t in enumerate((l1, l2, l3, l4)))
-        p4 = s.refinenet4.hip_block(i4, None, l3.shape[2:])
-        p3 = s.refinenet3.hip_block(p4, i3, l2.shape[2:])
-        p2 = s.refinenet2.hip_block(p3, i2, l1.shape[2:])
+        return self._hip_refine_images(i1, i2, i3, i4, patch_h, patch_w)
+
+    def _hip_refine_images(self, i1, i2, i3, i4, patch_h, patch_w):
+        s = self.scratch
+        ins = self.__dict__.setdefault('_hip_in', {})
+        p4 = s.refinenet4.hip_block(i4, None, i3.shape[2:])
+        p3 = s.refinenet3.hip_block(p4, i3, i2.shape[2:])
+        p2 = s.refinenet2.hip_block(p3, i2, i1.shape[2:])
         p1 = s.refinenet1.hip_block(p2, i1, None)
         o = _hip_cache(self, 'output_conv1', s.output_conv1)(p1)
         size = (int(patch_h * 14), int(patch_w * 14))
@@ -303,5 +402,16 @@ class DepthAnythingV2Adaptor(nn.Module):
 
     def forward(self, x):
         patch_h, patch_w = x.shape[-2] // 14, x.shape[-1] // 14
+        if (self.head_dtype == torch.bfloat16 and x.is_cuda
+                and not torch.is_grad_enabled() and not self.training):
+            # native: the encoder hands over LayerNormed bf16 token rows of the four
+            # taps, the head consumes them without a PyTorch op in between
+            taps = self.pretrained.intermediate_rows(
+                x, self.intermediate_layer_idx[self.encoder])
+            if taps is not None and self.depth_head.hip_front_ok(taps[0]):
+                B = x.shape[0]
+                depth = self.depth_head.hip_forward(taps, B, taps[0].shape[0] // B,
+                                                    patch_h, patch_w)
+                return {'metric_depth': (depth.float() * self.max_depth).squeeze(1)}
         depth = self.decode(self.encode(x), patch_h, patch_w)
         return {'metric_depth': depth.squeeze(1)}

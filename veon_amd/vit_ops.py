@@ -30,6 +30,23 @@ def to_bf16(x):
     return out
 
 
+def patchify(img, patch, skip=0, kpad=None):
+    """img fp32 (B,C,H,W) -> bf16 [B*(skip + h*w), kpad]: the conv-weight-ordered
+    p x p patches as GEMM rows, ``skip`` zero rows in front of every image."""
+    dev = _dev(img)
+    img = img.contiguous().float()
+    B, C, H, W = img.shape
+    k = C * patch * patch
+    kpad = kpad or (k + 63) // 64 * 64
+    out = torch.empty((B * (skip + (H // patch) * (W // patch)), kpad), dtype=torch.bfloat16,
+                      device=dev)
+    with _lib.on_device(dev):
+        st = _lib.lib().veon_vit_patchify(_lib.ptr(img), _lib.ptr(out), B, C, H, W, patch,
+                                          skip, kpad, _lib.stream_ptr(dev))
+    _lib.check(st, 'veon_vit_patchify')
+    return out
+
+
 def layernorm(x, weight, bias, eps=1e-6, out=None):
     """x fp32 [..., d] -> bf16 [..., d] (nn.LayerNorm over the last dim)."""
     dev = _dev(x, weight, bias)
