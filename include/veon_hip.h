@@ -352,7 +352,8 @@ int veon_two_hot_depth(int BN, int H, int W, int ds, int D, float lo, float step
  *                      4: A.W^T * gamma[N] + bias[N] -> bf16 out (a 1x1x1
  *                         convolution + eval-mode BatchNorm);  5: the same + ReLU
  *                         (the ConvModules of PredHead3DOcc / PredHead3DSem,
- *                         align_net_occ3d.py:431-534).
+ *                         align_net_occ3d.py:431-534);  6: sigmoid(4) - 0.5 (the
+ *                         output activation of PredHead3DSem, :528-533).
  * veon_vit_attention : qkv bf16 [B,T,3,H,64] (q pre-scaled) -> out bf16
  *                      [B,T,H*64] = softmax(q k^T + bias) v, flash style.
  *                      bias (optional) fp32 [.,.,T,T] with batch / head strides
@@ -473,6 +474,18 @@ int veon_image_unpack(const void *padded, void *nchw, int nchw_is_bf16, int B,
 int veon_image_resize_bilinear(const void *in_padded, void *out_padded, int B,
                                int C, int Yi, int Xi, int Yo, int Xo,
                                void *stream);
+/* Tail of the occupancy path in one kernel (semantic_net/san_in_veon_temporal.py:
+ * 196-211 + detectors/veon_temporal.py:219-227): sem (B,Q,zi,yi,xi) and bin
+ * (B,2,zi,yi,xi) fp32 logits, each addressed through five ELEMENT strides
+ * {b, c, z, y, x} (so the channels-last rows of the heads' GEMMs are read in place),
+ * are upsampled trilinearly (align_corners=False) to (Zo,Yo,Xo):
+ *   sem_out (B,Q,Zo,Yo,Xo), bin_out (B,2,Zo,Yo,Xo) fp32 contiguous,
+ *   cls_out (B,Xo,Yo,Zo) int64 = argmax_c softmax(sem_out) where
+ *     softmax(bin_out)[0] > 0.5 (and the best score > 0), else Q (= free). */
+int veon_occ_classify(const float *sem, const int64_t *sem_strides, int Q,
+                      const float *bin, const int64_t *bin_strides, int B, int zi,
+                      int yi, int xi, int Zo, int Yo, int Xo, float *sem_out,
+                      float *bin_out, int64_t *cls_out, void *stream);
 /* ViT token rows -> padded image, with the pixel shuffle of a ConvTranspose2d(k = s,
  * stride = s) folded in (DPTHead.resize_layers[0:2], depth_anything/dpt.py:55-72:
  * the transposed convolution itself is a GEMM over the tokens whose output row holds

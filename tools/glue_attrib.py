@@ -39,6 +39,24 @@ def main():
     for name, mod in net.named_modules():
         if name and name.count('.') < depth:
             wrap(mod, 'M:' + name)
+
+    def wrap_method(obj, attr, label):
+        inner = getattr(obj, attr)
+
+        def fn(*a, **k):
+            with record_function(label):
+                return inner(*a, **k)
+        setattr(obj, attr, fn)
+    # stages that are plain methods, not sub-module calls
+    for obj, attr in ((net, 'estimate_depth'), (net, 'clip_features'), (net, '_tail'),
+                      (net, '_classify'), (net.occ_decoder, 'prepare_depth'),
+                      (net.occ_decoder, 'prepare_meta'), (net.occ_decoder, 'fuse'),
+                      (net.depth_model.pretrained, 'intermediate_rows'),
+                      (net.depth_model.depth_head, 'hip_forward'),
+                      (net.clip_rec_head, 'update_remaining_clip_feats'),
+                      (net.view_transformer, '_lift_maxpool')):
+        if hasattr(obj, attr):
+            wrap_method(obj, attr, 'M:%s()' % attr)
     with torch.no_grad():
         for _ in range(3):
             net(images, geom)
@@ -62,14 +80,15 @@ def main():
         for k in ks:
             if '::k_' in k.name or k.name.startswith('k_'):
                 continue   # ours
-            acc[(where, ev.name)][0] += k.duration
-            acc[(where, ev.name)][1] += 1
+            op = ev.name if ev.name.startswith('aten::') else k.name[:44]
+            acc[(where, op)][0] += k.duration
+            acc[(where, op)][1] += 1
             kern[k.name[:70]][0] += k.duration
             kern[k.name[:70]][1] += 1
     total = sum(v[0] for v in acc.values())
     print('device kernels launched through aten ops: %.1f us per forward' % (total / n))
     for (where, op), (us, c) in sorted(acc.items(), key=lambda kv: -kv[1][0])[:70]:
-        print('%8.1f us %5.1f x  %-28s %s' % (us / n, c / n, op, where))
+        print('%8.1f us %5.1f x  %-44s %s' % (us / n, c / n, op, where))
     print('--- by kernel')
     for name, (us, c) in sorted(kern.items(), key=lambda kv: -kv[1][0])[:40]:
         print('%8.1f us %5.1f x  %s' % (us / n, c / n, name))

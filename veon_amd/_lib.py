@@ -77,6 +77,7 @@ _SIGNATURES = {
     'veon_image_dot': (_ci, [_vp, _vp, _cf, _vp] + [_ci] * 5 + [_vp]),
     'veon_tokens_to_image': (_ci, [_vp, _i64] + [_ci] * 6 + [_vp, _ci, _vp]),
     'veon_image_subsample': (_ci, [_vp, _vp] + [_ci] * 5 + [_vp]),
+    'veon_occ_classify': (_ci, [_vp, _vp, _ci, _vp, _vp] + [_ci] * 7 + [_vp, _vp, _vp, _vp]),
     'veon_image_pack_bf16': (_ci, [_vp, _ci, _vp] + [_ci] * 4 + [_vp]),
     'veon_image_unpack': (_ci, [_vp, _vp, _ci] + [_ci] * 4 + [_vp]),
     'veon_alloc_contiguous': (_ci, [_vp, _i64]),

@@ -366,3 +366,28 @@ def image_dot(img, w, bias, act='none'):
             {'none': 0, 'relu': 1, 'sigmoid': 2}[act], _lib.stream_ptr(dev))
     _lib.check(st, 'veon_image_dot')
     return out
+
+
+def occ_classify(sem_low, bin_low, occ_size):
+    """Trilinear upsampling (align_corners=False) of the class logits ``sem_low``
+    (B,Q,z,y,x) and occupancy logits ``bin_low`` (B,2,z,y,x) -- fp32, ANY strides --
+    to ``occ_size``, plus the label volume of VEONTemporal.simple_test, in one kernel.
+    -> (sem_occ (B,Q,Z,Y,X), bin_occ (B,2,Z,Y,X), occ_pred_cls (B,X,Y,Z) int64)."""
+    import ctypes
+    dev = _lib.require_device(sem_low, bin_low)
+    assert sem_low.dtype == bin_low.dtype == torch.float32
+    B, Q, zi, yi, xi = sem_low.shape
+    assert tuple(bin_low.shape) == (B, 2, zi, yi, xi)
+    Zo, Yo, Xo = (int(v) for v in occ_size)
+    sem = torch.empty((B, Q, Zo, Yo, Xo), dtype=torch.float32, device=dev)
+    binv = torch.empty((B, 2, Zo, Yo, Xo), dtype=torch.float32, device=dev)
+    cls = torch.empty((B, Xo, Yo, Zo), dtype=torch.int64, device=dev)
+    s5 = ctypes.c_int64 * 5
+    ss, bs = s5(*sem_low.stride()), s5(*bin_low.stride())
+    with _lib.on_device(dev):
+        st = _lib.lib().veon_occ_classify(
+            _lib.ptr(sem_low), ctypes.cast(ss, ctypes.c_void_p), Q, _lib.ptr(bin_low),
+            ctypes.cast(bs, ctypes.c_void_p), B, zi, yi, xi, Zo, Yo, Xo, _lib.ptr(sem),
+            _lib.ptr(binv), _lib.ptr(cls), _lib.stream_ptr(dev))
+    _lib.check(st, 'veon_occ_classify')
+    return sem, binv, cls

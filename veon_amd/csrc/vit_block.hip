@@ -129,7 +129,8 @@ __global__ __launch_bounds__(256) void k_layernorm_v4(
 constexpr int BK = 64;
 
 enum { EPI_BF16 = 0, EPI_GELU = 1, EPI_QUICKGELU = 2, EPI_RESID = 3,
-       EPI_AFFINE = 4, EPI_AFFINE_RELU = 5 };
+       EPI_AFFINE = 4, EPI_AFFINE_RELU = 5,
+       EPI_AFFINE_SIGM = 6 };  // sigmoid(affine) - 0.5 = tanh(x/2)/2 (PredHead3DSem)
 
 __device__ __forceinline__ float quick_gelu(float x) {
   return x / (1.f + __expf(-1.702f * x));
@@ -143,7 +144,7 @@ __device__ __forceinline__ void gemm_epilogue_store(f32x4 a, int m, int n, int N
                                                     float* __restrict__ resid,
                                                     bf16_t* __restrict__ out) {
   float v[4] = {a[0], a[1], a[2], a[3]};
-  if (EPI == EPI_AFFINE || EPI == EPI_AFFINE_RELU) {
+  if (EPI == EPI_AFFINE || EPI == EPI_AFFINE_RELU || EPI == EPI_AFFINE_SIGM) {
     if (gamma != nullptr) {
       const float4 g4 = *reinterpret_cast<const float4*>(gamma + n);
       v[0] *= g4.x; v[1] *= g4.y; v[2] *= g4.z; v[3] *= g4.w;
@@ -168,6 +169,7 @@ __device__ __forceinline__ void gemm_epilogue_store(f32x4 a, int m, int n, int N
       if (EPI == EPI_GELU) v[k] = gelu_erf(v[k]);
       if (EPI == EPI_QUICKGELU) v[k] = quick_gelu(v[k]);
       if (EPI == EPI_AFFINE_RELU) v[k] = fmaxf(v[k], 0.f);
+      if (EPI == EPI_AFFINE_SIGM) v[k] = 0.5f * tanhf(0.5f * v[k]);
     }
     bf16x4 o;
     o[0] = (short)f2bf(v[0]); o[1] = (short)f2bf(v[1]);
@@ -198,7 +200,9 @@ __device__ __forceinline__ void gemm_epilogue_store8(f32x4 a, f32x4 b, int m, in
     v[4] *= g1.x; v[5] *= g1.y; v[6] *= g1.z; v[7] *= g1.w;
   };
   // same order of operations as gemm_epilogue_store
-  if ((EPI == EPI_AFFINE || EPI == EPI_AFFINE_RELU) && gamma != nullptr) scale8(gamma);
+  if ((EPI == EPI_AFFINE || EPI == EPI_AFFINE_RELU || EPI == EPI_AFFINE_SIGM) &&
+      gamma != nullptr)
+    scale8(gamma);
   if (bias != nullptr) {
     const float4 b0 = *reinterpret_cast<const float4*>(bias + n);
     const float4 b1 = *reinterpret_cast<const float4*>(bias + n + 4);
@@ -220,6 +224,7 @@ __device__ __forceinline__ void gemm_epilogue_store8(f32x4 a, f32x4 b, int m, in
       if (EPI == EPI_GELU) v[k] = gelu_erf(v[k]);
       if (EPI == EPI_QUICKGELU) v[k] = quick_gelu(v[k]);
       if (EPI == EPI_AFFINE_RELU) v[k] = fmaxf(v[k], 0.f);
+      if (EPI == EPI_AFFINE_SIGM) v[k] = 0.5f * tanhf(0.5f * v[k]);
     }
     uint4 o;
     o.x = pack_bf16(v[0], v[1]);
@@ -1025,8 +1030,9 @@ int veon_vit_gemm(const void* a_bf16, const void* w_bf16, const float* bias,
     // (the fp32 read-modify-write of the residual epilogue, issued by every
     // workgroup at the same time in a one-round grid, costs the big tiles more
     // than their main loop gains: measured 30 vs 25 us on the ViT-L proj)
-    const int sel = g_gemm_ring >= 0 ? g_gemm_ring
+    int sel = g_gemm_ring >= 0 ? g_gemm_ring
                     : epilogue == EPI_RESID ? 0 : gemm_ring_config(M, N, K);
+    if (epilogue == EPI_AFFINE_SIGM) sel = 0;   // small-tile kernel only
     if (sel > 0) {
 #define VEON_RING(EPI, WM, WN, MT, NT, S)                                             \
   do {                                                                                \
@@ -1095,6 +1101,7 @@ int veon_vit_gemm(const void* a_bf16, const void* w_bf16, const float* bias,
     case EPI_RESID: VEON_LAUNCH_GEMM_MT(EPI_RESID); break;
     case EPI_AFFINE: VEON_LAUNCH_GEMM_MT(EPI_AFFINE); break;
     case EPI_AFFINE_RELU: VEON_LAUNCH_GEMM_MT(EPI_AFFINE_RELU); break;
+    case EPI_AFFINE_SIGM: VEON_LAUNCH_GEMM_MT(EPI_AFFINE_SIGM); break;
     default: return VEON_ERR_BAD_ARG;
   }
 #undef VEON_LAUNCH_GEMM_MT

@@ -1,6 +1,6 @@
 from .align_net_body import (AlignBody3D, ConvModule3d, PredHead3DOcc,
-                             PredHead3DSem, ResBlock3D, semantic_inference_3d,
-                             semantic_inference_3d_fused)
+                             PredHead3DSem, ResBlock3D, classifier_logits_low,
+                             semantic_inference_3d, semantic_inference_3d_fused)
 from .align_net_occ3d import AlignNetOcc3D
 from .fusion_layers import (AddFusionLift, CatFusionLift, LayerNorm,
                             build_fusion_layer_lift)

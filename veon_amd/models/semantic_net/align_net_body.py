@@ -60,7 +60,7 @@ class ConvModule3d(NativeCacheMixin, nn.Module):
         return w, scale.contiguous(), shift.contiguous()
 
 
-def _pointwise(vol, cm, out_channels=None):
+def _pointwise(vol, cm, out_channels=None, epilogue=None):
     """1x1x1 ConvModule3d on a PaddedVolume as one GEMM over its rows (the halo
     rows get the bias/shift -- they are never unpacked)."""
     if '_hip' not in cm.__dict__ or cm.__dict__['_hip'] is None:
@@ -82,6 +82,9 @@ def _pointwise(vol, cm, out_channels=None):
         bufs[key] = conv3d_ops.PaddedVolume(B, npad, Z, Y, X, vol.device)
     out = bufs[key]
     epi = vit_ops.EPI_AFFINE_RELU if cm.activate is not None else vit_ops.EPI_AFFINE
+    if epilogue is not None:
+        assert cm.activate is None
+        epi = epilogue
     vit_ops.linear(vol.rows, w, sh, epi, out=out.rows, gamma=sc)
     return out
 
@@ -113,7 +116,9 @@ class _PredHead3D(nn.Module):
             return True
         return x.is_cuda and not self.training and not torch.is_grad_enabled()
 
-    def _run(self, x, return_volume=False):
+    def _run(self, x, return_volume=False, last_epilogue=None):
+        """``last_epilogue``: GEMM epilogue of the LAST conv on the native path (the
+        caller's output activation fused in); ignored by the PyTorch path."""
         if not self._hip_ok(x):
             if isinstance(x, conv3d_ops.PaddedVolume):
                 x = conv3d_ops.unpack(x)
@@ -121,8 +126,9 @@ class _PredHead3D(nn.Module):
                 x = cm(x)
             return x
         vol = x if isinstance(x, conv3d_ops.PaddedVolume) else conv3d_ops.pack(x)
-        for cm in self._chain():
-            vol = _pointwise(vol, cm)
+        chain = self._chain()
+        for cm in chain:
+            vol = _pointwise(vol, cm, epilogue=last_epilogue if cm is chain[-1] else None)
         if return_volume:
             return vol
         out = conv3d_ops.unpack(vol)
@@ -168,10 +174,12 @@ class PredHead3DSem(_PredHead3D):
         """``return_volume`` (MFMA path only): keep the result -- sigmoid - 0.5
         applied in place on the bf16 rows -- as the PaddedVolume that
         ``semantic_inference_3d_fused`` consumes."""
+        if return_volume and self._hip_ok(x):
+            # sigmoid(x) - 0.5 = tanh(x/2)/2 in the last GEMM's epilogue (fp32, before
+            # the bf16 rounding; halo rows are never read)
+            return self._run(x, True, last_epilogue=vit_ops.EPI_AFFINE_SIGM)
         out = self._run(x, return_volume)
         if isinstance(out, conv3d_ops.PaddedVolume):
-            # sigmoid(x) - 0.5 = tanh(x/2)/2: no cancellation in bf16 (halo rows
-            # are never read)
             out.rows.mul_(0.5).tanh_().mul_(0.5)
             return out
         return out.sigmoid() - 0.5
@@ -186,14 +194,10 @@ def semantic_inference_3d(ov_classifier_weight, feat_occ, occ_size):
     return torch.einsum('qc,bczhw->bqzhw', ov_classifier_weight, feat)
 
 
-def semantic_inference_3d_fused(ov_classifier_weight, feat_occ, occ_size):
-    """Same logits with the two linear maps swapped: classify at the head's
-    resolution (one GEMM over the voxels: C -> Q classes), then upsample Q
-    channels instead of C (768 -> ~20: the 2 GB upsampled feature volume of the
-    reference is never formed).  Interpolation weights are per-channel and sum
-    to one, the classifier is per-voxel linear, so the results agree up to
-    rounding.  ``feat_occ``: (B,C,Z,Y,X) tensor or the PaddedVolume of
-    ``PredHead3DSem(..., return_volume=True)`` (GEMM on MFMA, fp32 logits)."""
+def classifier_logits_low(ov_classifier_weight, feat_occ):
+    """Class logits at the head's resolution: (B,Q,z,y,x) fp32 -- for a PaddedVolume
+    (``PredHead3DSem(..., return_volume=True)``) a strided view of the GEMM's
+    channels-last rows (MFMA, fp32 logits), otherwise the einsum."""
     W = ov_classifier_weight
     Q, C = W.shape
     if isinstance(feat_occ, conv3d_ops.PaddedVolume):
@@ -208,10 +212,20 @@ def semantic_inference_3d_fused(ov_classifier_weight, feat_occ, occ_size):
             vit_ops.linear_residual_(logits, vol.rows, wp.to(torch.bfloat16).contiguous())
         else:   # a K the MFMA tile does not divide (toy widths): rocBLAS, same operands
             logits = vol.rows.float() @ wp.to(torch.bfloat16).float().t()
-        low = logits.view(B, Z + 2, Y + 2, X + 2, qp)[:, 1:-1, 1:-1, 1:-1, :Q] \
+        return logits.view(B, Z + 2, Y + 2, X + 2, qp)[:, 1:-1, 1:-1, 1:-1, :Q] \
             .permute(0, 4, 1, 2, 3)
-    else:
-        low = torch.einsum('qc,bczhw->bqzhw', W, feat_occ)
+    return torch.einsum('qc,bczhw->bqzhw', W, feat_occ)
+
+
+def semantic_inference_3d_fused(ov_classifier_weight, feat_occ, occ_size):
+    """Same logits with the two linear maps swapped: classify at the head's
+    resolution (one GEMM over the voxels: C -> Q classes), then upsample Q
+    channels instead of C (768 -> ~20: the 2 GB upsampled feature volume of the
+    reference is never formed).  Interpolation weights are per-channel and sum
+    to one, the classifier is per-voxel linear, so the results agree up to
+    rounding.  ``feat_occ``: (B,C,Z,Y,X) tensor or the PaddedVolume of
+    ``PredHead3DSem(..., return_volume=True)`` (GEMM on MFMA, fp32 logits)."""
+    low = classifier_logits_low(ov_classifier_weight, feat_occ)
     return nn.functional.interpolate(low, size=tuple(occ_size), mode='trilinear',
                                      align_corners=False)
 

@@ -285,12 +285,49 @@ class PatchEmbed(nn.Module):
                               stride=patch_size, bias=bias)
         self.norm = nn.LayerNorm(embed_dim) if norm_layer else nn.Identity()
 
+    def _native_ok(self, x):
+        p = self.patch_size
+        return (x.is_cuda and not self.training and not torch.is_grad_enabled()
+                and self.flatten and p[0] == p[1]
+                and (self.proj.in_channels * p[0] * p[1]) % 64 == 0
+                and self.proj.out_channels % 8 == 0 and x.dtype == torch.float32)
+
     def forward(self, x):
+        if self._native_ok(x):
+            # kernel = stride: the patches as bf16 GEMM rows, one MFMA GEMM onto a
+            # zeroed fp32 token matrix (+ bias)
+            from ... import vit_ops
+            if '_hip' not in self.__dict__ or self.__dict__['_hip'] is None:
+                d = self.proj.out_channels
+                self.__dict__['_hip'] = (
+                    vit_ops.to_bf16(self.proj.weight.detach().float().view(d, -1)),
+                    None if self.proj.bias is None
+                    else self.proj.bias.detach().float().contiguous())
+            w, b = self.__dict__['_hip']
+            B, _, H, W = x.shape
+            p = self.patch_size[0]
+            h, wd = H // p, W // p
+            a = vit_ops.patchify(x, p, 0, w.shape[1])
+            out = torch.zeros((B, h * wd, w.shape[0]), dtype=torch.float32, device=x.device)
+            vit_ops.linear_residual_(out.view(B * h * wd, -1), a, w, b)
+            return self.norm(out), (h, wd)
         x = self.proj(x)
         _, c, h, w = x.shape
         if self.flatten:
             x = x.flatten(2).transpose(1, 2)
         return self.norm(x), (h, w)
+
+    def train(self, mode=True):
+        self.__dict__['_hip'] = None
+        return super().train(mode)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self.__dict__['_hip'] = None
+        return super()._load_from_state_dict(*args, **kwargs)
+
+    def _apply(self, fn, *args, **kwargs):
+        self.__dict__['_hip'] = None
+        return super()._apply(fn, *args, **kwargs)
 
 
 class HighresSideAdaptorNetwork(nn.Module):

@@ -35,7 +35,7 @@ import torch.nn.functional as F
 
 from .builder import build_neck
 from .semantic_net import (AlignNetOcc3D, ClipRecHead, ClipVisualTrunk,
-                           semantic_inference_3d_fused)
+                           classifier_logits_low, semantic_inference_3d_fused)
 from .semantic_net.hsa_network import HighresSideAdaptorNetwork
 
 
@@ -217,6 +217,14 @@ class VeonOccupancyPath(nn.Module):
         return self._classify(bin_occ, feat)
 
     def _classify(self, bin_occ, feat):
+        from .. import conv3d_ops
+        W = self.ov_classifier_weight
+        if bin_occ.is_cuda and not torch.is_grad_enabled() and bin_occ.shape[1] == 2:
+            # upsampling x2, both softmaxes, arg-max and the label volume: one kernel
+            low = classifier_logits_low(W, feat)
+            sem_occ, bin_up, occ = conv3d_ops.occ_classify(low.float(), bin_occ.float(),
+                                                           self.occ_size)
+            return {'bin_occ': bin_up, 'sem_occ': sem_occ, 'occ_pred_cls': occ}
         sem_occ = semantic_inference_3d_fused(self.ov_classifier_weight, feat, self.occ_size)
         bin_occ = F.interpolate(bin_occ, size=tuple(self.occ_size), mode='trilinear',
                                 align_corners=False)

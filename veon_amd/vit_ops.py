@@ -12,6 +12,7 @@ from . import _lib
 
 EPI_BF16, EPI_GELU, EPI_QUICKGELU, EPI_RESID = 0, 1, 2, 3
 EPI_AFFINE, EPI_AFFINE_RELU = 4, 5
+EPI_AFFINE_SIGM = 6     # sigmoid(gamma * x + bias) - 0.5
 
 
 def _dev(*ts):
