@@ -460,6 +460,9 @@ int veon_conv3d_k3_bf16(const void *in_padded, const void *w_bf16,
  * (mmdet3d/models/depth_anything/dpt.py:39-150, util/blocks.py) when the head
  * runs in bf16.
  */
+/* experiment knob of tools/body_bench.py (ablations of the conv kernels' loads;
+ * non-zero flags give WRONG results): 0 = normal. */
+void veon_conv_debug_set(int flags);
 int veon_conv2d_k3_bf16(const void *in_padded, const void *w_bf16,
                         const float *scale, const float *shift,
                         const void *resid_padded, void *out_padded, int B, int Y,

@@ -29,6 +29,13 @@ def main():
     print('conv3d_k3 BN+ReLU        %8.1f us  %6.1f TF/s (%4.1f%% of %.0f)' % (us, fl / us / 1e6, 100 * fl / us / 1e6 / PEAK, PEAK))
     us = timeit(lambda: conv3d_ops.conv3d_k3(vol, wp, sc, sc, resid=vol, relu=True, out=out), iters=20)
     print('conv3d_k3 BN+id+ReLU     %8.1f us  %6.1f TF/s (%4.1f%%)' % (us, fl / us / 1e6, 100 * fl / us / 1e6 / PEAK))
+    from veon_amd import _lib
+    for flags, what in ((1, 'A slab every 3rd tap'), (2, 'W slab once'), (3, 'both'),
+                        (4, 'no MFMA'), (7, 'no MFMA, few loads')):
+        _lib.lib().veon_conv_debug_set(flags)
+        us = timeit(lambda: conv3d_ops.conv3d_k3(vol, wp, sc, sc, relu=True, out=out), iters=20)
+        print('  ablation %d (%s): %8.1f us' % (flags, what, us))
+    _lib.lib().veon_conv_debug_set(0)
     print('pack %.1f us  unpack %.1f us' % (timeit(lambda: conv3d_ops.pack(x, out=vol)),
                                             timeit(lambda: conv3d_ops.unpack(vol))))
     body = AlignBody3D(C, 4).to(dev).eval()

@@ -35,7 +35,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv3d_k3(
     const bf16_t* __restrict__ in, const bf16_t* __restrict__ W,
     const float* __restrict__ scale, const float* __restrict__ shift,
     const bf16_t* __restrict__ resid, bf16_t* __restrict__ out, int planes,
-    int Zp, int Yp, int Xp, int Cin, int Cout, int kd) {
+    int Zp, int Yp, int Xp, int Cin, int Cout, int kd, int abl) {
   constexpr int BM = WM * 16 * MT;
   constexpr int CBN = 64 * WN;
   constexpr int NW = WM * WN;              // waves
@@ -110,14 +110,18 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv3d_k3(
     bf16_t* dA = smem + buf * BUF_ELEMS;
     bf16_t* dW = dA + A_ELEMS;
     const int64_t ao = a_off(kt);
+    // ablation (tools/body_bench.py, wrong results): 1 = activation slab only for
+    // every third tap, 2 = weight slab only once
+    const bool doA = !(abl & 1) || (kt / cpk) % 3 == 0;
+    const bool doW = !(abl & 2) || kt == 0;
 #pragma unroll
     for (int j = 0; j < AP; ++j)
-      if (wave + j * NW < APIECES)  // wave-uniform
+      if (doA && wave + j * NW < APIECES)  // wave-uniform
         __builtin_amdgcn_global_load_lds((gptr_t)(srcA[j] + ao),
                                          (lptr_t)(dA + (wave + j * NW) * 512), 16, 0, 0);
 #pragma unroll
     for (int j = 0; j < WP; ++j)
-      if (wave + j * NW < WPIECES)
+      if (doW && wave + j * NW < WPIECES)
         __builtin_amdgcn_global_load_lds((gptr_t)(srcW[j] + kt * CBK),
                                          (lptr_t)(dW + (wave + j * NW) * 512), 16, 0, 0);
   };
@@ -170,8 +174,216 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv3d_k3(
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
     if (kt + 1 < nk) dma(buf ^ 1, kt + 1);
-    compute(buf);
+    if (!(abl & 4)) compute(buf);
     __syncthreads();  // next slab landed (vmcnt drained) and this one released
+  }
+
+  // epilogue: lane owns 8 consecutive features of one voxel per tile pair
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int m = m0 + wm * (16 * MT) + i * 16 + fr;
+    if (m >= M) continue;
+    const int p = m / YX, rem = m - p * YX;
+    const int y = rem / Xp, x = rem - y * Xp, z = p % Zp;
+    const bool interior = (kd == 1 || (z >= 1 && z <= Zp - 2)) && y >= 1 &&
+                          y <= Yp - 2 && x >= 1 && x <= Xp - 2;
+#pragma unroll
+    for (int p2 = 0; p2 < 2; ++p2) {
+      const int n = n0 + wn * 64 + p2 * 32 + fg * 8;  // Cout % 8 == 0
+      if (n >= Cout) continue;
+      const f32x4 a0 = acc[i][2 * p2], a1 = acc[i][2 * p2 + 1];
+      float v[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+      if (scale != nullptr) {
+        const float4 s0 = *reinterpret_cast<const float4*>(scale + n);
+        const float4 s1 = *reinterpret_cast<const float4*>(scale + n + 4);
+        v[0] *= s0.x; v[1] *= s0.y; v[2] *= s0.z; v[3] *= s0.w;
+        v[4] *= s1.x; v[5] *= s1.y; v[6] *= s1.z; v[7] *= s1.w;
+      }
+      if (shift != nullptr) {
+        const float4 b0 = *reinterpret_cast<const float4*>(shift + n);
+        const float4 b1 = *reinterpret_cast<const float4*>(shift + n + 4);
+        v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
+        v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+      }
+      if (RESID) {
+        const bf16x8 r8 =
+            *reinterpret_cast<const bf16x8*>(resid + (int64_t)m * Cout + n);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] += bf2f((bf16_t)r8[k]);
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        if (ACT == 1) v[k] = fmaxf(v[k], 0.f);
+        if (ACT == 2) v[k] = gelu_erf(v[k]);
+        if (!interior) v[k] = 0.f;
+      }
+      const uint4 o = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]),
+                       pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])};
+      *reinterpret_cast<uint4*>(out + (int64_t)m * Cout + n) = o;
+    }
+  }
+}
+
+// The same tile with the activation slab shared by the three x-taps of a filter
+// row: the taps (dz, dy, -1 / 0 / +1) read rows m + off - 1, m + off, m + off + 1 of
+// the padded grid, i.e. ONE slab of BM + 2 rows shifted by a row.  The slab is
+// fetched once per (dz, dy, channel chunk) and the MFMA operand reads step through it
+// (the XOR swizzle is keyed on the slab row, so a shifted read stays conflict-free);
+// only the weight slab changes per tap.  L2 -> LDS traffic per three k-steps drops
+// from 3 (BM + BN) to (BM + 2) + 3 BN rows: 1.6x less at 336 x 256 -- the loads
+// alone took 183 us of this kernel's 268 at the body's shape (tools/body_bench.py
+// ablations), the arithmetic alone 220.
+// Tile = (WM*16*MT) voxels x (64*WN) features, WM x WN waves of (16*MT) x 64 each.
+template <int WM, int WN, int MT, int ACT, bool RESID>
+__global__ __launch_bounds__(64 * WM * WN) void k_conv3d_k3_ax(
+    const bf16_t* __restrict__ in, const bf16_t* __restrict__ W,
+    const float* __restrict__ scale, const float* __restrict__ shift,
+    const bf16_t* __restrict__ resid, bf16_t* __restrict__ out, int planes,
+    int Zp, int Yp, int Xp, int Cin, int Cout, int kd) {
+  constexpr int BM = WM * 16 * MT;
+  constexpr int CBN = 64 * WN;
+  constexpr int NW = WM * WN;              // waves
+  constexpr int NT = 64 * NW;              // threads
+  // DMA pieces (8 rows = 1 KiB each) are dealt round-robin to the waves:
+  // wave w issues pieces w, w + NW, ... of each slab
+  constexpr int AROWS = BM + 8;   // BM + 2 used, rounded up to whole 8-row pieces
+  constexpr int APIECES = AROWS / 8, WPIECES = CBN / 8;
+  constexpr int AP = (APIECES + NW - 1) / NW;  // per wave, last may be absent
+  constexpr int WP = (WPIECES + NW - 1) / NW;
+  constexpr int A_ELEMS = AROWS * CBK;
+  constexpr int CW_ELEMS = CBN * CBK;
+  extern __shared__ __attribute__((aligned(16))) bf16_t smem[];  // [2][A] [2][W]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int YX = Yp * Xp;
+  const int M = planes * YX;  // planes = B * Zp
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * CBN;
+  // kd = 3: 3x3x3 taps on a grid padded in z, y and x; kd = 1: the 2-D case,
+  // 3x3 taps on [B][Yp][Xp] images (Zp = planes per image = 1, no z halo)
+  const int K = 9 * kd * Cin;
+
+  // tile entirely inside z-halo planes: nothing to contract, store zeros
+  if (kd == 3) {
+    const int p0 = m0 / YX;
+    const int mlast = (m0 + BM - 1 < M ? m0 + BM - 1 : M - 1);
+    const int p1 = mlast / YX;
+    const int z0 = p0 % Zp, z1 = p1 % Zp;
+    const bool h0 = z0 == 0 || z0 == Zp - 1, h1 = z1 == 0 || z1 == Zp - 1;
+    if (h0 && h1 && p1 - p0 <= 1) {
+      // BM rows x CBN features of bf16, 16 bytes per lane-store
+      constexpr int CPR = CBN / 8;  // 16-byte chunks per row
+      for (int i = tid; i < BM * CPR; i += NT) {
+        const int r = i / CPR, c8 = (i % CPR) * 8;
+        if (m0 + r < M && n0 + c8 < Cout)
+          *reinterpret_cast<uint4*>(out + (int64_t)(m0 + r) * Cout + n0 + c8) =
+              make_uint4(0u, 0u, 0u, 0u);
+      }
+      return;
+    }
+  }
+
+  // DMA map as k_gemm_bf16: a wave instruction fills 8 rows of a slab; lane l
+  // lands in row r = 8*piece + l/8, physical chunk l%8, and fetches logical
+  // chunk (l%8) ^ (r&7).  Activation rows are NOT clamped (guard rows).
+  // 32-bit element offsets (the launcher checks the extents): 64-bit pointers per
+  // piece cost the 168-VGPR budget of the 12-wave tile a spill
+  int srcA[AP], srcW[WP];
+#pragma unroll
+  for (int j = 0; j < AP; ++j) {
+    const int r = (wave + j * NW) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ (r & 7);
+    srcA[j] = (m0 - 1 + r) * Cin + c * 8;
+  }
+#pragma unroll
+  for (int j = 0; j < WP; ++j) {
+    const int r = (wave + j * NW) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ (r & 7);
+    const int gn = n0 + r < Cout ? n0 + r : Cout - 1;
+    srcW[j] = gn * K + c * 8;
+  }
+  const int cpk = Cin / CBK;  // channel chunks
+  // group g = (dz, dy, channel chunk): one activation slab, three weight slabs
+  const int ngroups = 3 * kd * cpk;
+  auto dma_a = [&](int g) {
+    bf16_t* dA = smem + (g & 1) * A_ELEMS;
+    const int zy = g / cpk, cc = (g - zy * cpk) * CBK;
+    const int dz = kd == 3 ? zy / 3 - 1 : 0, dy = zy % 3 - 1;
+    const int ao = ((dz * Yp + dy) * Xp) * Cin + cc;
+#pragma unroll
+    for (int j = 0; j < AP; ++j)
+      if (wave + j * NW < APIECES)  // wave-uniform
+        __builtin_amdgcn_global_load_lds((gptr_t)(in + (srcA[j] + ao)),
+                                         (lptr_t)(dA + (wave + j * NW) * 512), 16, 0, 0);
+  };
+  auto dma_w = [&](int st) {   // st = 3 g + dx
+    bf16_t* dW = smem + 2 * A_ELEMS + (st & 1) * CW_ELEMS;
+    const int g = st / 3, dx = st - g * 3;
+    const int zy = g / cpk, cc = (g - zy * cpk) * CBK;
+    const int wk = (zy * 3 + dx) * Cin + cc;
+#pragma unroll
+    for (int j = 0; j < WP; ++j)
+      if (wave + j * NW < WPIECES)
+        __builtin_amdgcn_global_load_lds((gptr_t)(W + (srcW[j] + wk)),
+                                         (lptr_t)(dW + (wave + j * NW) * 512), 16, 0, 0);
+  };
+
+  f32x4 acc[MT][4];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  int offW[4];
+  const int ra0 = wm * (16 * MT) + fr;   // + 16 i + dx: the slab row of this lane
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    // tiles are paired, weight rows interleaved in groups of four: the accumulator
+    // rows 4 fg .. 4 fg + 3 of tiles 2p and 2p + 1 are the 8 consecutive features
+    // 32 p + 8 fg + 0..7 (16-byte epilogue accesses instead of 8-byte ones)
+    const int rw = wn * 64 + (i / 2) * 32 + (fr / 4) * 8 + (i & 1) * 4 + (fr & 3);
+    offW[i] = rw * CBK + ((fg ^ (rw & 7)) * 8);
+  }
+
+  auto compute = [&](int g, int st, int dx) {
+    const bf16_t* tA = smem + (g & 1) * A_ELEMS;
+    const bf16_t* tW = smem + 2 * A_ELEMS + (st & 1) * CW_ELEMS;
+    int offA[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int ra = ra0 + i * 16 + dx;
+      offA[i] = ra * CBK + ((fg ^ (ra & 7)) * 8);
+    }
+#pragma unroll
+    for (int ks = 0; ks < CBK / 32; ++ks) {
+      bf16x8 fa[MT], fw[4];
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+        fa[i] = *reinterpret_cast<const bf16x8*>(tA + (offA[i] ^ (ks * 32)));
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        fw[j] = *reinterpret_cast<const bf16x8*>(tW + (offW[j] ^ (ks * 32)));
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          // acc[i][j][reg] = C[voxel i*16 + fr][feature j*16 + 4*fg + reg]
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i],
+                                                               acc[i][j], 0, 0, 0);
+    }
+  };
+  dma_a(0);
+  dma_w(0);
+  __syncthreads();
+  for (int g = 0; g < ngroups; ++g) {
+#pragma unroll 1   // (unrolled, the three bodies' operand offsets spill at 168 VGPRs)
+    for (int dx = 0; dx < 3; ++dx) {
+      const int st = 3 * g + dx;
+      if (dx == 0 && g + 1 < ngroups) dma_a(g + 1);
+      if (st + 1 < 3 * ngroups) dma_w(st + 1);
+      compute(g, st, dx);
+      __syncthreads();  // next slabs landed (vmcnt drained) and these released
+    }
   }
 
   // epilogue: lane owns 8 consecutive features of one voxel per tile pair
@@ -500,6 +712,8 @@ int64_t veon_conv3d_guard_rows(int Y, int X) {
   return (int64_t)(Y + 2) * (X + 2) + (X + 2) + 1 + 512;
 }
 
+static int g_conv_abl = 0;
+
 static int conv_k3_impl(int kd, const void* in_padded, const void* w_bf16,
                         const float* scale, const float* shift,
                         const void* resid_padded, void* out_padded, int B, int Z,
@@ -554,8 +768,23 @@ static int conv_k3_impl(int kd, const void* in_padded, const void* w_bf16,
   const bf16_t* R = static_cast<const bf16_t*>(resid_padded);
   bf16_t* O = static_cast<bf16_t*>(out_padded);
   const int planes = B * (Z + 2 * pz);
+  // the slab-sharing kernel addresses activations and weights by 32-bit offsets
+  const bool fits32 = (M + 2 * veon_conv3d_guard_rows(Y, X)) * Cin < 0x7fffffffLL &&
+                      (int64_t)Cout * 9 * kd * Cin < 0x7fffffffLL;
 #define VEON_LAUNCH_CONV(WM, WN, MT, ACT, RESID)                              \
   do {                                                                         \
+    constexpr int ldsx =                                                       \
+        2 * (WM * 16 * MT + 8 + 64 * WN) * CBK * (int)sizeof(bf16_t);          \
+    if (ldsx <= 160 * 1024 && !(g_conv_abl & 8) && fits32) {                   \
+      static const hipError_t attrx = hipFuncSetAttribute(                     \
+          reinterpret_cast<const void*>(&k_conv3d_k3_ax<WM, WN, MT, ACT, RESID>), \
+          hipFuncAttributeMaxDynamicSharedMemorySize, ldsx);                   \
+      if (attrx != hipSuccess) return VEON_ERR_LAUNCH;                         \
+      hipLaunchKernelGGL((k_conv3d_k3_ax<WM, WN, MT, ACT, RESID>), grid,      \
+                         dim3(64 * WM * WN), ldsx, s, I, Wt, scale, shift, R, O, \
+                         planes, Z + 2 * pz, Y + 2, X + 2, Cin, Cout, kd);     \
+      break;                                                                   \
+    }                                                                          \
     constexpr int lds =                                                        \
         2 * (WM * 16 * MT + 64 * WN) * CBK * (int)sizeof(bf16_t);              \
     static const hipError_t attr = hipFuncSetAttribute(                        \
@@ -564,7 +793,8 @@ static int conv_k3_impl(int kd, const void* in_padded, const void* w_bf16,
     if (attr != hipSuccess) return VEON_ERR_LAUNCH;                            \
     hipLaunchKernelGGL((k_conv3d_k3<WM, WN, MT, ACT, RESID>), grid,           \
                        dim3(64 * WM * WN), lds, s, I, Wt, scale, shift, R, O,  \
-                       planes, Z + 2 * pz, Y + 2, X + 2, Cin, Cout, kd);       \
+                       planes, Z + 2 * pz, Y + 2, X + 2, Cin, Cout, kd,        \
+                       g_conv_abl);                                            \
   } while (0)
 #define VEON_TILE_IS(a, b, c) (wm == a && wn == b && mt == c)
 #define VEON_LAUNCH_CONV_T(ACT, RESID)                                        \
@@ -593,6 +823,8 @@ static int conv_k3_impl(int kd, const void* in_padded, const void* w_bf16,
 #undef VEON_LAUNCH_CONV
   return launch_status();
 }
+
+void veon_conv_debug_set(int flags) { g_conv_abl = flags; }
 
 int veon_conv3d_k3_bf16(const void* in_padded, const void* w_bf16,
                         const float* scale, const float* shift,

@@ -66,6 +66,10 @@ __device__ __forceinline__ float blend(const float* __restrict__ p, const Corner
                   ay.l1 * (ax.l0 * p[k.o[6]] + ax.l1 * p[k.o[7]]));
 }
 
+// VEC4: the class logits are channels-last (channel stride 1, rows 16-byte aligned,
+// at least 4*ceil(Q/4) floats per row): four classes per 16-byte corner load -- the
+// kernel is bound by the number of cache lines its gathers touch, 3.4x fewer so.
+template <bool VEC4>
 __global__ __launch_bounds__(256) void k_occ_classify(
     const float* __restrict__ sem, Strides5 ss, int Q, const float* __restrict__ bin,
     Strides5 bs, int B, int zi, int yi, int xi, int Zo, int Yo, int Xo, float scz,
@@ -95,14 +99,44 @@ __global__ __launch_bounds__(256) void k_occ_classify(
   const float* sp = sem + b * ss.b;
   float* so = sem_out + (int64_t)b * Q * plane + v;
   const Corners ks = corners(ss, az, ay, ax);
+  if (VEC4) {
+#pragma unroll 1
+    for (int c = 0; c < Q; c += 4) {
+      float4 k4[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) k4[q] = *reinterpret_cast<const float4*>(sp + c + ks.o[q]);
+      float val4[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        auto at = [&](int q) { return reinterpret_cast<const float*>(&k4[q])[e]; };
+        val4[e] = az.l0 * (ay.l0 * (ax.l0 * at(0) + ax.l1 * at(1)) +
+                           ay.l1 * (ax.l0 * at(2) + ax.l1 * at(3))) +
+                  az.l1 * (ay.l0 * (ax.l0 * at(4) + ax.l1 * at(5)) +
+                           ay.l1 * (ax.l0 * at(6) + ax.l1 * at(7)));
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (c + e < Q) {
+          const float val = val4[e];
+          so[(int64_t)(c + e) * plane] = val;
+          bad |= val != val;
+          if (val > vmax) {
+            vmax = val;
+            cls = c + e;
+          }
+        }
+      }
+    }
+  } else {
 #pragma unroll 2
-  for (int c = 0; c < Q; ++c) {
-    const float val = blend(sp + c * ss.c, ks, az, ay, ax);
-    so[(int64_t)c * plane] = val;
-    bad |= val != val;
-    if (val > vmax) {
-      vmax = val;
-      cls = c;
+    for (int c = 0; c < Q; ++c) {
+      const float val = blend(sp + c * ss.c, ks, az, ay, ax);
+      so[(int64_t)c * plane] = val;
+      bad |= val != val;
+      if (val > vmax) {
+        vmax = val;
+        cls = c;
+      }
     }
   }
   const bool scored = !bad && vmax < INFINITY && vmax > -INFINITY;
@@ -147,8 +181,17 @@ extern "C" int veon_occ_classify(const float* sem, const int64_t* sem_strides, i
   // ATen: scale = in / out in float (area_pixel_compute_scale, no scale_factor given)
   const float scz = (float)zi / (float)Zo, scy = (float)yi / (float)Yo,
               scx = (float)xi / (float)Xo;
-  hipLaunchKernelGGL(k_occ_classify, dim3((unsigned)blocks), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), sem, ss, Q, bin, bs, B, zi, yi, xi,
-                     Zo, Yo, Xo, scz, scy, scx, sem_out, bin_out, cls_out);
+  const int q4 = (Q + 3) / 4 * 4;
+  const bool vec4 = ss.c == 1 && (reinterpret_cast<uintptr_t>(sem) & 15u) == 0 &&
+                    ss.b % 4 == 0 && ss.z % 4 == 0 && ss.y % 4 == 0 && ss.x % 4 == 0 &&
+                    ss.x >= q4;
+  if (vec4)
+    hipLaunchKernelGGL(k_occ_classify<true>, dim3((unsigned)blocks), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), sem, ss, Q, bin, bs, B, zi, yi,
+                       xi, Zo, Yo, Xo, scz, scy, scx, sem_out, bin_out, cls_out);
+  else
+    hipLaunchKernelGGL(k_occ_classify<false>, dim3((unsigned)blocks), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), sem, ss, Q, bin, bs, B, zi, yi,
+                       xi, Zo, Yo, Xo, scz, scy, scx, sem_out, bin_out, cls_out);
   return launch_status();
 }
