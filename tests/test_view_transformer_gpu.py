@@ -429,3 +429,50 @@ def test_degenerate_single_voxel_prepare_is_ordered_and_bounded():
     assert torch.equal(rf.long(), (p // (D * H * W)) * (H * W) + p % (H * W))
     print('single-voxel prepare of %d points: %.1f ms' % (P, dt * 1e3))
     assert dt < 2.0, dt
+
+
+def test_sparse_lift_drops_the_clamped_tail_within_tolerance():
+    """Opt-in sparse lift: with VEON's soft two-hot depth the points
+    below ``sparse_depth_eps`` never enter the sort.  Far fewer points are pooled, and
+    every voxel sum stays within eps * (sum of |feat| of the dropped points of that
+    voxel) of the full lift -- checked against that bound, computed by pooling |feat|
+    with the dropped weights replaced by eps."""
+    torch.manual_seed(0)
+    size, cams, C = (256, 704), 6, 64
+    vt = build_neck(dict(type='LSSViewTransformerRaw', grid_config=synthetic.GRID_VEON,
+                         input_size=size, out_channels=C, collapse_z=False,
+                         accelerate=False, ds_feat=[1, 1, 1])).to(DEV).eval()
+    vt.sync_free = True
+    hf, wf = size[0] // 16, size[1] // 16
+    inp = [t.to(DEV) for t in synthetic.rig_inputs(synthetic.make_rig(1, cams, size))]
+    metric = torch.rand(1, cams, hf, wf, device=DEV) * 45 + 1.5
+    depth = vt.get_two_hot_depth(metric).contiguous()          # (1, N, D, hf, wf)
+    feat = torch.randn(1, cams, C, hf, wf, device=DEV)
+    eps = 1e-6
+    with torch.no_grad():
+        full = vt._lift_sync_free([feat] + inp, depth, feat).clone()
+        kept_full = int(_prep_counts(vt)[0])
+        vt.sparse_depth_eps = eps
+        sparse = vt._lift_sync_free([feat] + inp, depth, feat).clone()
+        kept_sparse = int(_prep_counts(vt)[0])
+        # the bound: pool |feat| with weight eps at every DROPPED point
+        vt.sparse_depth_eps = None
+        dropped = torch.where(depth < eps, torch.full_like(depth, eps),
+                              torch.zeros_like(depth))
+        bound = vt._lift_sync_free([feat.abs()] + inp, dropped, feat.abs())
+        vt.sparse_depth_eps = 1e-30                     # keeps every point: same bits
+        same = vt._lift_sync_free([feat] + inp, depth, feat)
+    assert torch.equal(same, full)
+    assert kept_sparse * 4 < kept_full, (kept_sparse, kept_full)   # measured 6.2x at D = 112
+    err = (sparse - full).abs()
+    assert bool((err <= bound * 1.001 + 1e-7).all()), (err.max().item(), bound.max().item())
+    assert err.max().item() < 1e-4 * full.abs().max().item()
+    print('sparse lift: %d of %d points pooled, max |diff| %.2e (max |V| %.2f)'
+          % (kept_sparse, kept_full, err.max().item(), full.abs().max().item()))
+
+
+def _prep_counts(vt):
+    from veon_amd import lss_prepare_hip
+    ws = [w for k, w in lss_prepare_hip._WORKSPACES.items()
+          if k[1] == int(vt.grid_size[0] * vt.grid_size[1] * vt.grid_size[2])]
+    return ws[-1].counts.tolist()

@@ -5,7 +5,7 @@ check the replays against eager outputs, then capture a SECOND graph (the S2 lif
 step of bench.py) and replay the first again -- the situation in which a lift
 graph faulted in round 1 -- and time eager vs replay.
 
-    python tools/graph_path.py [vitb|vitl] [--veon-res]
+    python tools/graph_path.py [vitb|vitl] [--veon-res] [--sparse]
 """
 import os
 import sys
@@ -33,7 +33,10 @@ def main():
     size = (512, 1408) if '--veon-res' in sys.argv else (256, 704)
     dev = 'cuda:0'
     torch.manual_seed(0)
-    net = VeonOccupancyPath(input_size=size, encoder=enc).to(dev).eval()
+    kw = dict(VeonOccupancyPath.VEON_L) if enc == 'vitl' else dict(encoder='vitb')
+    if '--sparse' in sys.argv:      # opt-in sparse lift
+        kw['sparse_lift_eps'] = 1e-6
+    net = VeonOccupancyPath(input_size=size, **kw).to(dev).eval()
     geom = [t.to(dev) for t in synthetic.rig_inputs(synthetic.make_rig(1, 6, size))]
     images = torch.randn(1, 6, 3, *size, device=dev)
     with torch.no_grad():

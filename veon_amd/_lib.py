@@ -98,6 +98,8 @@ _SIGNATURES = {
     'veon_lss_prepare_workspace_bytes': (_i64, [_i64, _i64]),
     'veon_lss_prepare_cameras': (_ci, [_ci] * 5 + [_vp] * 8 + [_vp] * 3 + [_i64, _vp, _i64, _ci]
                                  + [_vp] * 8 + [_vp]),
+    'veon_lss_prepare_cameras_sparse': (_ci, [_ci] * 5 + [_vp] * 8 + [_vp] * 3
+                                        + [_i64, _vp, _i64, _ci] + [_vp] * 8 + [_vp, _cf, _vp]),
     'veon_lss_prepare': (_ci, [_ci] * 5 + [_vp] * 9 + [_vp] * 3 + [_i64, _vp, _i64]
                          + [_vp] * 7 + [_vp]),
 }

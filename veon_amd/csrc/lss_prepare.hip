@@ -180,7 +180,7 @@ template <int FROM>
 __global__ __launch_bounds__(kBlock) void k_voxel_keys(
     Geometry g, CameraRaw cr, const float* __restrict__ coor, GridF gr, int N, int D,
     int H, int W, int64_t n_bins, int* __restrict__ keys, int* __restrict__ slots,
-    int* __restrict__ hist) {
+    int* __restrict__ hist, const float* __restrict__ depth_w, float depth_eps) {
   __shared__ float cam[21];  // post_rots_inv[9], combine[9], trans[3]
   const int bn = blockIdx.y;
   if constexpr (FROM == 2) {
@@ -237,6 +237,10 @@ __global__ __launch_bounds__(kBlock) void k_voxel_keys(
   }
   int key = voxel_key(gr, c, bn / N);
   if (key >= n_bins) key = -1;  // cannot happen for consistent grids; be safe
+  // opt-in sparse lift: a point whose depth weight is below the caller's threshold
+  // (the clamped tail of VEON's soft two-hot depth, ~1e-7 per bin) is dropped here
+  // and never sorted, ranked or pooled
+  if (depth_w != nullptr && key >= 0 && depth_w[p] < depth_eps) key = -1;
   if (!valid) key = -2;
   // Neighbouring pixels of one image row mostly fall into the same voxel: a run of
   // consecutive lanes with one key takes ONE returning atomic (by its first lane,
@@ -533,7 +537,7 @@ static int prepare_impl(int B, int N, int D, int H, int W, const float* coor,
                         int64_t workspace_bytes, int hist_is_zero, int* ranks_bev,
                         int* ranks_depth, int* ranks_feat, int* interval_starts,
                         int* interval_lengths, int* plan, int* vstart, int* counts,
-                        void* stream) {
+                        const float* depth_w, float depth_eps, void* stream) {
   if (B <= 0 || N <= 0 || D <= 0 || H <= 0 || W <= 0 || voxels_per_batch <= 0)
     return VEON_ERR_BAD_ARG;
   if (!grid_lower || !grid_interval || !grid_size || !workspace || !ranks_bev ||
@@ -574,13 +578,13 @@ static int prepare_impl(int B, int N, int D, int H, int W, const float* coor,
   const dim3 kgrid((unsigned)((dhw + kBlock - 1) / kBlock), (unsigned)(B * N));
   if (coor)
     hipLaunchKernelGGL(k_voxel_keys<1>, kgrid, dim3(kBlock), 0, s, g, cr, coor, gr, N,
-                       D, H, W, n_bins, w.keys, w.slots, w.hist);
+                       D, H, W, n_bins, w.keys, w.slots, w.hist, depth_w, depth_eps);
   else if (raw)
     hipLaunchKernelGGL(k_voxel_keys<2>, kgrid, dim3(kBlock), 0, s, g, cr, coor, gr, N,
-                       D, H, W, n_bins, w.keys, w.slots, w.hist);
+                       D, H, W, n_bins, w.keys, w.slots, w.hist, depth_w, depth_eps);
   else
     hipLaunchKernelGGL(k_voxel_keys<0>, kgrid, dim3(kBlock), 0, s, g, cr, coor, gr, N,
-                       D, H, W, n_bins, w.keys, w.slots, w.hist);
+                       D, H, W, n_bins, w.keys, w.slots, w.hist, depth_w, depth_eps);
   const int64_t tiles_per_batch = voxels_per_batch / kTileV;
   hipLaunchKernelGGL(k_scan_reduce, dim3(n_scan_blocks), dim3(kBlock), 0, s,
                      w.hist, n_bins, w.block_sums);
@@ -610,7 +614,8 @@ int veon_lss_prepare(int B, int N, int D, int H, int W, const float* coor,
                       combine, trans, bda, nullptr, nullptr, nullptr, grid_lower,
                       grid_interval, grid_size, voxels_per_batch, workspace,
                       workspace_bytes, 0, ranks_bev, ranks_depth, ranks_feat,
-                      interval_starts, interval_lengths, plan, nullptr, counts, stream);
+                      interval_starts, interval_lengths, plan, nullptr, counts, nullptr,
+                      0.f, stream);
 }
 
 int veon_lss_prepare_cameras(int B, int N, int D, int H, int W, const float* xs,
@@ -630,7 +635,25 @@ int veon_lss_prepare_cameras(int B, int N, int D, int H, int W, const float* xs,
                       grid_interval, grid_size, voxels_per_batch, workspace,
                       workspace_bytes, hist_is_zero, ranks_bev, ranks_depth,
                       ranks_feat, interval_starts, interval_lengths, plan, vstart,
-                      counts, stream);
+                      counts, nullptr, 0.f, stream);
+}
+
+int veon_lss_prepare_cameras_sparse(
+    int B, int N, int D, int H, int W, const float* xs, const float* ys, const float* ds,
+    const float* sensor2ego, const float* cam2imgs, const float* post_rots,
+    const float* post_trans, const float* bda, const float* grid_lower,
+    const float* grid_interval, const float* grid_size, int64_t voxels_per_batch,
+    void* workspace, int64_t workspace_bytes, int hist_is_zero, int* ranks_bev,
+    int* ranks_depth, int* ranks_feat, int* interval_starts, int* interval_lengths,
+    int* plan, int* vstart, int* counts, const float* depth_weights, float depth_eps,
+    void* stream) {
+  if (!sensor2ego || !depth_weights) return VEON_ERR_BAD_ARG;
+  return prepare_impl(B, N, D, H, W, nullptr, xs, ys, ds, nullptr, post_trans, nullptr,
+                      nullptr, bda, sensor2ego, cam2imgs, post_rots, grid_lower,
+                      grid_interval, grid_size, voxels_per_batch, workspace,
+                      workspace_bytes, hist_is_zero, ranks_bev, ranks_depth,
+                      ranks_feat, interval_starts, interval_lengths, plan, vstart,
+                      counts, depth_weights, depth_eps, stream);
 }
 
 }  // extern "C"

@@ -179,7 +179,7 @@ def prepare_device(dims, coor, geometry, lower, interval, gsize, device):
 
 
 def prepare_cameras(frustum, sensor2ego, cam2imgs, post_rots, post_trans, bda, lower,
-                    interval, gsize):
+                    interval, gsize, depth_weights=None, depth_eps=0.0):
     """The sync-free per-call prepare from the reference's camera tensors
     (get_lidar_coor's arguments) into the static LiftWorkspace: five launches, no
     allocation, no memset, no host sync.  Returns the workspace (a ``Prepared``
@@ -193,17 +193,27 @@ def prepare_cameras(frustum, sensor2ego, cam2imgs, post_rots, post_trans, bda, l
     s2e, k, pr, pt, bd = (_f32c(t) for t in (sensor2ego, cam2imgs, post_rots, post_trans,
                                               bda))
     glo, gstep, gsz = _grid_host(lower, interval, gsize)
-    with _lib.on_device(dev):
-        st = _lib.lib().veon_lss_prepare_cameras(
-            B, N, D, H, W, _lib.ptr(xs), _lib.ptr(ys), _lib.ptr(ds), _lib.ptr(s2e),
+    args = (B, N, D, H, W, _lib.ptr(xs), _lib.ptr(ys), _lib.ptr(ds), _lib.ptr(s2e),
             _lib.ptr(k), _lib.ptr(pr), _lib.ptr(pt), _lib.ptr(bd),
             ctypes.cast(glo, ctypes.c_void_p), ctypes.cast(gstep, ctypes.c_void_p),
             ctypes.cast(gsz, ctypes.c_void_p), vpb, _lib.ptr(ws.ws), ws.ws_bytes, 1,
             _lib.ptr(ws.ranks_bev), _lib.ptr(ws.ranks_depth), _lib.ptr(ws.ranks_feat),
             _lib.ptr(ws.interval_starts), _lib.ptr(ws.interval_lengths),
-            _lib.ptr(ws.plan), _lib.ptr(ws.vstart), _lib.ptr(ws.counts),
-            _lib.stream_ptr(dev))
-    _lib.check(st, 'veon_lss_prepare_cameras')
+            _lib.ptr(ws.plan), _lib.ptr(ws.vstart), _lib.ptr(ws.counts))
+    with _lib.on_device(dev):
+        if depth_weights is not None and depth_eps > 0.0:
+            # sparse lift: points whose depth weight is below depth_eps are not sorted
+            if (depth_weights.dtype != torch.float32 or not depth_weights.is_contiguous()
+                    or depth_weights.numel() != B * N * D * H * W
+                    or depth_weights.device != dev):
+                raise _lib.VeonHipError('depth_weights must be a contiguous fp32 '
+                                        '(B,N,D,H,W) tensor on the rig\'s device')
+            st = _lib.lib().veon_lss_prepare_cameras_sparse(
+                *args, _lib.ptr(depth_weights), float(depth_eps), _lib.stream_ptr(dev))
+            _lib.check(st, 'veon_lss_prepare_cameras_sparse')
+        else:
+            st = _lib.lib().veon_lss_prepare_cameras(*args, _lib.stream_ptr(dev))
+            _lib.check(st, 'veon_lss_prepare_cameras')
     return ws
 
 

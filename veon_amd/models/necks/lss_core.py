@@ -159,6 +159,18 @@ class LSSCore(_Base):
             bev_feat = torch.cat(bev_feat.unbind(dim=2), 1)
         return bev_feat
 
+    def _sparse_args(self, depth):
+        """``sparse_depth_eps`` (opt-in, default None = every frustum point, the
+        reference's sums to the bit): in the sync-free lift, points whose depth
+        weight is below it are dropped before the sort -- VEON's soft two-hot depth
+        puts ~1e-7 on all but a few of a pixel's D bins (include/veon_hip.h
+        ``veon_lss_prepare_cameras_sparse``).  Pooled sums then differ by at most
+        eps * sum|feat| over the dropped points."""
+        eps = getattr(self, 'sparse_depth_eps', None)
+        if not eps:
+            return {}
+        return dict(depth_weights=depth.contiguous().float(), depth_eps=float(eps))
+
     def _rows_beside_prepare(self, feat_l, depth):
         """Inside a hipGraph capture the feature layout change (NCHW -> pixel rows)
         is put on a forked stream, so the graph runs it BESIDE the prepare kernels
@@ -181,7 +193,8 @@ class LSSCore(_Base):
         feat_l, join = self._rows_beside_prepare(feat.permute(0, 1, 3, 4, 2), depth)
         pre = _prep._HIP_PREPARE.prepare_cameras(
             self.frustum, sensor2ego, cam2imgs, post_rots, post_trans, bda,
-            self.grid_lower_bound, self.grid_interval, self.grid_size)
+            self.grid_lower_bound, self.grid_interval, self.grid_size,
+            **self._sparse_args(depth))
         join()
         shape = self._bev_feat_shape(depth.shape[0], feat.shape[2])
         out = None
@@ -213,7 +226,8 @@ class LSSCore(_Base):
             feat, join = self._rows_beside_prepare(feat, depth)
             pre = _prep._HIP_PREPARE.prepare_cameras(
                 self.frustum, sensor2ego, cam2imgs, post_rots, post_trans, bda,
-                self.grid_lower_bound, self.grid_interval, self.grid_size)
+                self.grid_lower_bound, self.grid_interval, self.grid_size,
+                **self._sparse_args(depth))
             join()
             return _bp.bev_pool_v2_maxpool(
                 depth, feat, pre.ranks_depth, pre.ranks_feat, pre.ranks_bev,

@@ -53,7 +53,8 @@ class VeonOccupancyPath(nn.Module):
                  clip_heads=12, clip_first_tail=9, clip_proj_dim=512, embed_dim=256,
                  occ_size=(16, 200, 200), bf16_heads=True, two_streams=True,
                  hsa_dim=384, hsa_fusion_map=('0->3->3', '1->6->6', '2->9->9'),
-                 num_temporal=1, clip_patch=16, clip_image=224, side_adapter=None):
+                 num_temporal=1, clip_patch=16, clip_image=224, side_adapter=None,
+                 sparse_lift_eps=None):
         super().__init__()
         from .. import synthetic
         grid_config = grid_config or synthetic.GRID_VEON
@@ -91,6 +92,9 @@ class VeonOccupancyPath(nn.Module):
             type='LSSViewTransformerRaw', grid_config=grid_config, input_size=input_size,
             out_channels=embed_dim, collapse_z=False, ds_feat=[2, 2, 2]))
         self.view_transformer.sync_free = True
+        # opt-in: drop frustum points whose two-hot depth weight is below this before
+        # the sort (lss_core._sparse_args); None = the reference's sums to the bit
+        self.view_transformer.sparse_depth_eps = sparse_lift_eps
         self.occ_decoder = AlignNetOcc3D(
             clip_dim=clip_width, hsa_dim=hsa_dim, embed_dim=embed_dim,
             clip_outdim=clip_proj_dim, layer_lifting_map=['%d->0->0' % clip_layers],
