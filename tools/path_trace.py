@@ -20,8 +20,10 @@ def main():
     dev, size = 'cuda:0', (256, 704)
     torch.manual_seed(0)
     temporal = os.environ.get('TEMPORAL') == '1'
-    net = VeonOccupancyPath(input_size=size, encoder='vitb',
-                            num_temporal=2 if temporal else 1).to(dev).eval()
+    kw = (dict(VeonOccupancyPath.VEON_L) if os.environ.get('ENC') == 'vitl'
+          else dict(encoder='vitb'))
+    net = VeonOccupancyPath(input_size=size, num_temporal=2 if temporal else 1,
+                            **kw).to(dev).eval()
     net.two_streams = os.environ.get('TWO_STREAMS', '0') == '1'
     geom = [t.to(dev) for t in synthetic.rig_inputs(synthetic.make_rig(1, 6, size))]
     images = torch.randn(1, 6, 3, *size, device=dev)
