@@ -404,7 +404,11 @@ def main():
             # A replay of this two-kernel graph costs more on the GPU front end than
             # the two plain launches do on the host on some boxes (and less on
             # others): measure both briefly, run the timed steps with the faster.
-            def probe(fn, n=40):
+            # (the probe runs as many steps as the timed region: plain launches win a
+            # 40-step probe by 4 us but pay a fixed ~25 ms runtime stall somewhere
+            # between 500 and 2000 steps -- 48.3 us/step at K = 500, 61 at K = 2000 --
+            # which a replayed graph does not)
+            def probe(fn, n=max(40, min(args.steps, 4000))):
                 for _ in range(5):
                     fn()
                 torch.cuda.synchronize()
@@ -413,8 +417,12 @@ def main():
                     fn()
                 torch.cuda.synchronize()
                 return (time.perf_counter() - t) / n * 1e6
+            # the first pass absorbs a one-time stall of the HIP runtime (25-60 ms,
+            # somewhere in the first ~2500 plain launches of a process)
+            first = probe(step, max(3000, min(args.steps, 4000)))
             launch_probe = {'hipGraph_us': round(probe(graph.replay), 2),
-                            'eager_us': round(probe(step), 2)}
+                            'eager_us': round(probe(step), 2),
+                            'eager_first_pass_us': round(first, 2)}
             if launch_probe['eager_us'] < launch_probe['hipGraph_us']:
                 run, graph = step, None
 
