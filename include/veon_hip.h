@@ -488,6 +488,14 @@ int veon_conv2d_k3_bf16(const void *in_padded, const void *w_bf16,
                         const float *scale, const float *shift,
                         const void *resid_padded, void *out_padded, int B, int Y,
                         int X, int Cin, int Cout, int relu, void *stream);
+/* The same with stride 2 (Conv2d(k = 3, stride = 2, padding = 1): DPTHead.resize_layers[3],
+ * depth_anything/dpt.py:69-72): in = padded image (B, Cin, Yin, Xin), out = padded image
+ * (B, Cout, ceil(Yin/2), ceil(Xin/2)); only the needed output pixels are computed (the
+ * activation rows of a tile are gathered by per-lane DMA addresses). */
+int veon_conv2d_k3s2_bf16(const void *in_padded, const void *w_bf16, const float *scale,
+                          const float *shift, const void *resid_padded, void *out_padded,
+                          int B, int Yin, int Xin, int Cin, int Cout, int act,
+                          void *stream);
 /* (B,C,Y,X) fp32 or bf16 (nchw_is_bf16) <-> interior of the padded image grid */
 int veon_image_pack_bf16(const void *nchw, int nchw_is_bf16, void *padded, int B,
                          int C, int Y, int X, void *stream);

@@ -513,3 +513,39 @@ def test_layernorm_tokens_to_padded_image_and_convblock_fusions():
         apart = blk(ln(x), (Y, X)) + x
     rel = ((fused - apart).norm() / apart.norm()).item()
     assert rel < 5e-3, rel
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape', [(2, 64, 64, 9, 13), (1, 128, 192, 18, 50), (2, 64, 8, 5, 4)])
+def test_conv2d_stride2_matches_torch(shape):
+    """veon_conv2d_k3s2_bf16 (Conv2d k=3, s=2, p=1; DPTHead.resize_layers[3]) against
+    torch's conv2d on the same bf16-rounded operands; odd and even sizes; also equal
+    to the stride-1 kernel sampled at every second pixel."""
+    import torch
+    import torch.nn.functional as F
+    from veon_amd import conv3d_ops
+    B, Cin, Cout, Y, X = shape
+    torch.manual_seed(0)
+    x = torch.randn(B, Cin, Y, X, device='cuda:0').bfloat16()
+    w = (torch.randn(Cout, Cin, 3, 3, device='cuda:0') * (9 * Cin) ** -0.5)
+    bias = torch.randn(Cout, device='cuda:0')
+    wp = conv3d_ops.pack_weight2d(w)
+    shift = torch.zeros(wp.shape[0], device='cuda:0')
+    shift[:Cout] = bias
+    img = conv3d_ops.pack_image(x)
+    out = conv3d_ops.conv2d_k3s2(img, wp, None, shift)
+    got = conv3d_ops.unpack_image(out, torch.float32, Cout)
+    ref = F.conv2d(x.float(), w.bfloat16().float(), bias, stride=2, padding=1)
+    assert got.shape == ref.shape
+    err = (got - ref).abs()
+    assert bool((err <= 2 ** -7 * ref.abs() + 2e-3 * ref.pow(2).mean().sqrt()).all()), err.max()
+    full = conv3d_ops.unpack_image(conv3d_ops.conv2d_k3(img, wp, None, shift), torch.float32,
+                                   Cout)
+    # (bit-equal only when both kernels sum the taps in the same order: Cin = 64)
+    torch.testing.assert_close(got, full[:, :, ::2, ::2], rtol=2 ** -7, atol=2e-2)
+    if Cin == 64:
+        assert torch.equal(got, full[:, :, ::2, ::2])
+    # the halo of the result is zero: it can feed the next conv directly
+    rows = out.rows.view(B, out.shape[2] + 2, out.shape[3] + 2, -1)
+    assert not rows[:, 0].any() and not rows[:, -1].any()
+    assert not rows[:, :, 0].any() and not rows[:, :, -1].any()

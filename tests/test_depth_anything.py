@@ -162,8 +162,8 @@ def test_dpt_head_bf16_mfma_convs_match_autocast():
 @pytest.mark.gpu
 def test_native_depth_forward_tokens_to_depth():
     """forward() with head_dtype = bf16: LayerNormed bf16 token rows of the four taps
-    -> projection / transposed-conv GEMMs -> pixel-shuffle pack -> 3x3 convs (stride
-    2 as stride 1 + subsample) -> fusion blocks, no PyTorch op in the head.  Against
+    -> projection / transposed-conv GEMMs -> pixel-shuffle pack -> 3x3 convs (one of
+    them stride 2) -> fusion blocks, no PyTorch op in the head.  Against
     the fp32 head on the same encoder output, and against PyTorch's bf16 autocast of
     the head (the error budget)."""
     import torch
@@ -184,7 +184,7 @@ def test_native_depth_forward_tokens_to_depth():
         before = dict(_lib.CALLS)
         got = m(x)['metric_depth']
         ran = {k: _lib.CALLS.get(k, 0) - before.get(k, 0)
-               for k in ('veon_tokens_to_image', 'veon_image_subsample')}
+               for k in ('veon_tokens_to_image', 'veon_conv2d_k3s2_bf16')}
         ok = dpt.DPTHead.hip_front_ok
         dpt.DPTHead.hip_front_ok = lambda self, rows: False
         okc = dpt._hip_convs_ok
@@ -195,7 +195,7 @@ def test_native_depth_forward_tokens_to_depth():
             dpt.DPTHead.hip_front_ok, dpt._hip_convs_ok = ok, okc
         m.head_dtype = None
         ref32 = m(x)['metric_depth']
-    assert ran == {'veon_tokens_to_image': 4, 'veon_image_subsample': 1}, ran
+    assert ran == {'veon_tokens_to_image': 4, 'veon_conv2d_k3s2_bf16': 1}, ran
     assert got.shape == ref32.shape == (2, 70, 98)
     err_hip = ((got - ref32).norm() / ref32.norm()).item()
     err_amp = ((amp - ref32).norm() / ref32.norm()).item()

@@ -26,6 +26,19 @@ with torch.no_grad():
     print('MIOpen bf16  %.2f ms' % timeit(lambda: dav2.decode(feats, 18, 50)))
     dpt._hip_convs_ok = ok
     # single pieces at the big shapes
+    for mt in (1, 2, 3, 4):     # forced tile heights (veon_conv_debug_set bits 8..15)
+        _lib.lib().veon_conv_debug_set(mt << 8)
+        print('forced mt = %d: head %.3f ms' % (mt, timeit(lambda: dav2.decode(feats, 18, 50))))
+        for (B, Cin, Cout, H, W) in ((6, 128, 128, 72, 200), (6, 128, 128, 144, 400),
+                                     (6, 128, 64, 144, 400), (6, 64, 32, 252, 700)):
+            xx = torch.randn(B, Cin, H, W, device=dev).bfloat16()
+            hc = dpt._HipConv(torch.nn.Conv2d(Cin, Cout, 3, 1, 1).to(dev))
+            img = conv3d_ops.pack_image(xx)
+            fl = 2.0 * B * H * W * Cin * Cout * 9
+            t_c = timeit(lambda: hc(img, relu=True))
+            print('   %s: conv %.1f us (%.0f TF/s)' % ((B, Cin, Cout, H, W), t_c * 1e3,
+                                                       fl / t_c / 1e9))
+    _lib.lib().veon_conv_debug_set(0)
     for (B, Cin, Cout, H, W) in ((6, 128, 128, 72, 200), (6, 128, 64, 144, 400), (6, 64, 32, 252, 700)):
         xx = torch.randn(B, Cin, H, W, device=dev).bfloat16()
         conv = torch.nn.Conv2d(Cin, Cout, 3, 1, 1).to(dev)

@@ -262,6 +262,27 @@ def conv2d_k3(img, w_packed, scale=None, shift=None, resid=None, relu=False,
     return out
 
 
+def conv2d_k3s2(img, w_packed, scale=None, shift=None, out=None, act=None):
+    """3x3 stride-2 pad-1 convolution on a PaddedImage -> PaddedImage
+    (B, Cout, ceil(Y/2), ceil(X/2)), epilogue as ``conv2d_k3``."""
+    dev = _lib.require_device(img.storage, w_packed)
+    B, Cin, Y, X = img.shape
+    Cout = w_packed.shape[0]
+    assert w_packed.dtype == torch.bfloat16 and w_packed.is_contiguous()
+    assert w_packed.numel() == Cout * 9 * Cin
+    Yo, Xo = (Y + 1) // 2, (X + 1) // 2
+    if out is None:
+        out = PaddedImage(B, Cout, Yo, Xo, dev)
+    assert out.shape == (B, Cout, Yo, Xo) and out is not img
+    with _lib.on_device(dev):
+        st = _lib.lib().veon_conv2d_k3s2_bf16(
+            _lib.ptr(img.rows), _lib.ptr(w_packed), _lib.ptr(scale), _lib.ptr(shift),
+            _lib.ptr(None), _lib.ptr(out.rows), B, Y, X, Cin, Cout, _ACT[act],
+            _lib.stream_ptr(dev))
+    _lib.check(st, 'veon_conv2d_k3s2_bf16')
+    return out
+
+
 def image_layernorm(img, gamma, beta, eps, out=None, tokens=False, residual=None):
     """LayerNorm over the channels of every pixel of a PaddedImage.  ``tokens``
     False: -> PaddedImage (zero halo); True: -> fp32 tokens (B, Y*X, C), plus

@@ -35,7 +35,12 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv3d_k3(
     const bf16_t* __restrict__ in, const bf16_t* __restrict__ W,
     const float* __restrict__ scale, const float* __restrict__ shift,
     const bf16_t* __restrict__ resid, bf16_t* __restrict__ out, int planes,
-    int Zp, int Yp, int Xp, int Cin, int Cout, int kd, int abl) {
+    int Zp, int Yp, int Xp, int Cin, int Cout, int kd, int abl, int stride, int Ypi,
+    int Xpi) {
+  // stride 2 (kd == 1 only): planes / Yp / Xp describe the OUTPUT grid, Ypi / Xpi the
+  // padded input image; output pixel (y, x) reads the 3x3 neighbourhood of input
+  // pixel (2y, 2x).  The DMA source of a tile row is a per-lane pointer anyway, so the
+  // row map costs nothing in the k-loop.  stride 1: Ypi == Yp, Xpi == Xp.
   constexpr int BM = WM * 16 * MT;
   constexpr int CBN = 64 * WN;
   constexpr int NW = WM * WN;              // waves
@@ -89,7 +94,17 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv3d_k3(
   for (int j = 0; j < AP; ++j) {
     const int r = (wave + j * NW) * 8 + (lane >> 3);
     const int c = (lane & 7) ^ (r & 7);
-    srcA[j] = in + (int64_t)(m0 + r) * Cin + c * 8;
+    int64_t row = m0 + r;
+    if (stride != 1) {
+      const int mm = m0 + r < M ? m0 + r : M - 1;
+      const int p = mm / YX, rem = mm - p * YX;
+      const int yo = rem / Xp, xo = rem - yo * Xp;
+      int yi = stride * (yo - 1) + 1, xi = stride * (xo - 1) + 1;   // padded coordinates
+      yi = yi < 1 ? 1 : (yi > Ypi - 2 ? Ypi - 2 : yi);   // halo rows: any valid pixel
+      xi = xi < 1 ? 1 : (xi > Xpi - 2 ? Xpi - 2 : xi);   // (their result is zeroed)
+      row = ((int64_t)p * Ypi + yi) * Xpi + xi;
+    }
+    srcA[j] = in + row * Cin + c * 8;
   }
 #pragma unroll
   for (int j = 0; j < WP; ++j) {
@@ -103,7 +118,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv3d_k3(
     const int tap = kt / cpk;
     const int cc = (kt - tap * cpk) * CBK;
     const int dz = kd == 3 ? tap / 9 - 1 : 0, dy = (tap / 3) % 3, dx = tap % 3;
-    const int off = (dz * Yp + (dy - 1)) * Xp + (dx - 1);
+    const int off = (dz * Ypi + (dy - 1)) * Xpi + (dx - 1);
     return (int64_t)off * Cin + cc;
   };
   auto dma = [&](int buf, int kt) {
@@ -717,7 +732,12 @@ static int g_conv_abl = 0;
 static int conv_k3_impl(int kd, const void* in_padded, const void* w_bf16,
                         const float* scale, const float* shift,
                         const void* resid_padded, void* out_padded, int B, int Z,
-                        int Y, int X, int Cin, int Cout, int relu, void* stream) {
+                        int Y, int X, int Cin, int Cout, int relu, void* stream,
+                        int stride = 1, int Yin = 0, int Xin = 0) {
+  // Y, X: the OUTPUT grid; Yin, Xin: the input image of a strided 2-D conv
+  if (stride == 1) { Yin = Y; Xin = X; }
+  if (stride < 1 || stride > 2 || (stride == 2 && kd != 1) || Yin <= 0 || Xin <= 0)
+    return VEON_ERR_BAD_ARG;
   const int pz = kd == 3 ? 1 : 0;  // z halo planes on each side
   if (B <= 0 || Z <= 0 || Y <= 0 || X <= 0 || Cin <= 0 || Cout <= 0 ||
       Cin % CBK != 0 || Cout % 8 != 0 || !in_padded || !w_bf16 || !out_padded)
@@ -759,6 +779,14 @@ static int conv_k3_impl(int kd, const void* in_padded, const void* w_bf16,
       wm = cands[i].wm; wn = cands[i].wn; mt = cands[i].mt;
     }
   }
+  // 128-feature tiles: 128 rows (16 MFMAs per wave and k-step) beat 64 once the grid
+  // has several rounds either way -- measured 128 vs 166 us at 6 x 144 x 400 pixels,
+  // 40 vs 46 at 6 x 72 x 200 (tools/dpt_probe2.py); the rounds x rows estimate above
+  // cannot see that
+  if (!is_wide && !is_mid && Cout > 64 && M >= 65536) mt = 2;
+  // experiment knob (tools/dpt_probe2.py): bits 8..15 of veon_conv_debug_set force the
+  // tile height (mt) of the 128- and 64-feature tile classes
+  if (((g_conv_abl >> 8) & 0xff) != 0 && !is_wide && !is_mid) mt = (g_conv_abl >> 8) & 0xff;
   const int bm = wm * 16 * mt;
   const int64_t ncol = (Cout + 64 * wn - 1) / (64 * wn);
   const dim3 grid((unsigned)ncol, (unsigned)((M + bm - 1) / bm));
@@ -775,7 +803,7 @@ static int conv_k3_impl(int kd, const void* in_padded, const void* w_bf16,
   do {                                                                         \
     constexpr int ldsx =                                                       \
         2 * (WM * 16 * MT + 8 + 64 * WN) * CBK * (int)sizeof(bf16_t);          \
-    if (ldsx <= 160 * 1024 && !(g_conv_abl & 8) && fits32) {                   \
+    if (ldsx <= 160 * 1024 && !(g_conv_abl & 8) && fits32 && stride == 1) {    \
       static const hipError_t attrx = hipFuncSetAttribute(                     \
           reinterpret_cast<const void*>(&k_conv3d_k3_ax<WM, WN, MT, ACT, RESID>), \
           hipFuncAttributeMaxDynamicSharedMemorySize, ldsx);                   \
@@ -794,7 +822,7 @@ static int conv_k3_impl(int kd, const void* in_padded, const void* w_bf16,
     hipLaunchKernelGGL((k_conv3d_k3<WM, WN, MT, ACT, RESID>), grid,           \
                        dim3(64 * WM * WN), lds, s, I, Wt, scale, shift, R, O,  \
                        planes, Z + 2 * pz, Y + 2, X + 2, Cin, Cout, kd,        \
-                       g_conv_abl);                                            \
+                       g_conv_abl, stride, Yin + 2, Xin + 2);                  \
   } while (0)
 #define VEON_TILE_IS(a, b, c) (wm == a && wn == b && mt == c)
 #define VEON_LAUNCH_CONV_T(ACT, RESID)                                        \
@@ -807,6 +835,10 @@ static int conv_k3_impl(int kd, const void* in_padded, const void* w_bf16,
     else if (VEON_TILE_IS(4, 3, 3)) VEON_LAUNCH_CONV(4, 3, 3, ACT, RESID);    \
     else if (VEON_TILE_IS(8, 1, 1)) VEON_LAUNCH_CONV(8, 1, 1, ACT, RESID);    \
     else if (VEON_TILE_IS(8, 1, 2)) VEON_LAUNCH_CONV(8, 1, 2, ACT, RESID);    \
+    else if (VEON_TILE_IS(8, 1, 3)) VEON_LAUNCH_CONV(8, 1, 3, ACT, RESID);    \
+    else if (VEON_TILE_IS(8, 1, 4)) VEON_LAUNCH_CONV(8, 1, 4, ACT, RESID);    \
+    else if (VEON_TILE_IS(4, 2, 3)) VEON_LAUNCH_CONV(4, 2, 3, ACT, RESID);    \
+    else if (VEON_TILE_IS(4, 2, 4)) VEON_LAUNCH_CONV(4, 2, 4, ACT, RESID);    \
     else VEON_LAUNCH_CONV(4, 2, 1, ACT, RESID);                               \
   } while (0)
   if (relu == 1) {
@@ -840,6 +872,15 @@ int veon_conv2d_k3_bf16(const void* in_padded, const void* w_bf16,
                         int X, int Cin, int Cout, int relu, void* stream) {
   return conv_k3_impl(1, in_padded, w_bf16, scale, shift, resid_padded, out_padded,
                       B, 1, Y, X, Cin, Cout, relu, stream);
+}
+
+int veon_conv2d_k3s2_bf16(const void* in_padded, const void* w_bf16, const float* scale,
+                          const float* shift, const void* resid_padded, void* out_padded,
+                          int B, int Yin, int Xin, int Cin, int Cout, int act,
+                          void* stream) {
+  if (Yin <= 0 || Xin <= 0) return VEON_ERR_BAD_ARG;
+  return conv_k3_impl(1, in_padded, w_bf16, scale, shift, resid_padded, out_padded, B, 1,
+                      (Yin + 1) / 2, (Xin + 1) / 2, Cin, Cout, act, stream, 2, Yin, Xin);
 }
 
 static int pack_impl(bool unpack, int pz, int planar_bf16, const void* planar,

@@ -293,12 +293,10 @@ class DPTHead(NativeCacheMixin, nn.Module):
             img = conv3d_ops.tokens_to_image(x, T, T - patch_h * patch_w, patch_h, patch_w,
                                              sc, ocp, image(('lvl', i), ocp, sc * patch_h,
                                                             sc * patch_w))
-            if 'wc' in lv:   # 3x3 stride 2 = the stride-1 conv at every second pixel
-                full = conv3d_ops.conv2d_k3(img, lv['wc'], None, lv['bc'],
-                                            out=image(('s2', i), ocp, patch_h, patch_w))
-                img = conv3d_ops.image_subsample(
-                    full, 2, out=image(('sub', i), ocp, (patch_h + 1) // 2,
-                                       (patch_w + 1) // 2))
+            if 'wc' in lv:   # 3x3 stride 2: only the needed pixels (gathered DMA rows)
+                img = conv3d_ops.conv2d_k3s2(
+                    img, lv['wc'], None, lv['bc'],
+                    out=image(('s2', i), ocp, (patch_h + 1) // 2, (patch_w + 1) // 2))
             Y, X = img.shape[2:]
             outs.append(conv3d_ops.conv2d_k3(img, lv['wr'], None, lv['br'],
                                              out=image(('rn', i), lv['wr'].shape[0], Y, X)))
