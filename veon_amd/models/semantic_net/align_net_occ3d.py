@@ -98,12 +98,18 @@ class AlignNetOcc3D(nn.Module):
         return [t.squeeze(2) for t in torch.split(feats_2d, 1, dim=2)][0]
 
     # ------------------------------------------------------------------ fusion
+    def fuse_2d(self, block_idx, clip_features, supp_features, lift_shape):
+        """The 2-D half of ``fuse``: the fusion layer on the CLIP / HSA maps (needs no
+        depth, so a caller can issue it at the end of the semantic branch)."""
+        src_clip, src_ec = self.fusion_map[block_idx]
+        return self.fusion_layers['layer_%d' % block_idx](
+            supp_features[src_ec], clip_features[src_clip], lift_shape)
+
     def fuse(self, block_idx, x, clip_features, supp_features, depth, img_metas,
-             clip_shape, lift_shape, out_volume=None):
+             clip_shape, lift_shape, out_volume=None, fused=None):
         if block_idx in self.fusion_map:
-            src_clip, src_ec = self.fusion_map[block_idx]
-            fused = self.fusion_layers['layer_%d' % block_idx](
-                supp_features[src_ec], clip_features[src_clip], lift_shape)
+            if fused is None:
+                fused = self.fuse_2d(block_idx, clip_features, supp_features, lift_shape)
             feats_2d = self.prepare_feat_for_lifting(fused)
             if out_volume is not None:
                 return self.lss_view_transformer([feats_2d] + img_metas, depth,

@@ -153,33 +153,52 @@ class VeonOccupancyPath(nn.Module):
         return semantic_branch_2d(self.side_adapter_network, self.clip_rec_head,
                                   self.ov_classifier_weight, img, feats)
 
-    def _branches(self, images, depth=None):
+    def _branches(self, images, depth=None, metas=None):
         """Both encoder branches of one frame -> (CLIP feature dict, supp, depth).
         ``depth`` (B, N, H/2, W/2): cached metric depth (veon_amd/depth_cache.py)
         used instead of the depth encoder, as the reference's ``use_depth_pred``
-        data pipeline does."""
+        data pipeline does.  ``metas``: the decoder's camera tensors; their 4x4 algebra
+        (``prepare_meta``, ~14 tiny launches that depend on nothing else) is then issued
+        in front of the shorter semantic branch instead of on the critical path after
+        both branches; so is the decoder's 2-D fusion layer, which needs no depth.  Both are
+        then returned as a fourth and fifth value."""
         img = images.flatten(0, 1)
         n_cam = images.shape[1]
-        if depth is not None:
+        dec = self.occ_decoder
+        hf, wf = self.input_size[0] // 16, self.input_size[1] // 16
+
+        def prep():
+            return None if metas is None else dec.prepare_meta(metas)
+
+        def sem():   # CLIP -> HSA -> CLIP tail, then (fast path) the 2-D fusion layer
             feats, supp = self.clip_features(img)
-            return feats, supp, depth.to(img.device, torch.float32)
-        if self.two_streams and img.is_cuda:
+            fused = dec.fuse_2d(0, feats, [supp], (hf, wf)) if metas is not None else None
+            return feats, supp, fused
+        if depth is not None:
+            metas2 = prep()
+            feats, supp, fused = sem()
+            out = (feats, supp, depth.to(img.device, torch.float32))
+        elif self.two_streams and img.is_cuda:
             if self.__dict__['_side'] is None:
                 self.__dict__['_side'] = torch.cuda.Stream()
             side, cur = self.__dict__['_side'], torch.cuda.current_stream()
             side.wait_stream(cur)
             with torch.cuda.stream(side):
-                feats, supp = self.clip_features(img)
+                metas2 = prep()
+                feats, supp, fused = sem()
             depth = self.estimate_depth(img, n_cam)
             cur.wait_stream(side)
             if not torch.cuda.is_current_stream_capturing():
                 # (a captured forward keeps every tensor of the capture alive)
-                for t in list(feats.values()) + [supp]:
+                for t in (list(feats.values()) + [supp] + list(metas2 or [])
+                          + ([fused] if fused is not None else [])):
                     t.record_stream(cur)
+            out = (feats, supp, depth)
         else:
-            feats, supp = self.clip_features(img)
-            depth = self.estimate_depth(img, n_cam)
-        return feats, supp, depth
+            metas2 = prep()
+            feats, supp, fused = sem()
+            out = (feats, supp, self.estimate_depth(img, n_cam))
+        return out if metas is None else out + (metas2, fused)
 
     def lift_frame(self, images, img_metas, out_volume=None, depth=None):
         """Lifted, max-pooled volume of one frame before any 3-D layer
@@ -317,7 +336,6 @@ class VeonOccupancyPath(nn.Module):
         (the reference's ``occ_feat_prevs``).  Returns ``bin_occ`` / ``sem_occ`` at
         ``occ_size`` and ``occ_pred_cls``."""
         B, N = images.shape[:2]
-        feats, supp, depth = self._branches(images, depth)
         hf, wf = self.input_size[0] // 16, self.input_size[1] // 16
         sem_embed_ds = images.new_zeros((B * N, 1, hf, wf))   # shape carrier only
         metas = list(img_metas[:5]) + [img_metas[5][None]]
@@ -325,12 +343,13 @@ class VeonOccupancyPath(nn.Module):
         fast = (dec._fast_path(sem_embed_ds)
                 and self.view_transformer._can_fuse_ds(sem_embed_ds))
         if fast:   # keep the sem head's output as a padded volume for the classifier
+            feats, supp, depth, metas2, fused = self._branches(images, depth, metas)
             depth2 = dec.prepare_depth(depth)
-            metas2 = dec.prepare_meta(metas)
             vol = dec._lift_volume(depth2.shape[0], dec.layers_3d_body[0].conv1.conv.in_channels,
                                    images.device)
             x = dec.fuse(0, None, feats, [supp], depth2, metas2, None, (hf, wf),
-                         out_volume=vol)
+                         out_volume=vol, fused=fused)
             return self._tail(x, prev_volumes)
+        feats, supp, depth = self._branches(images, depth)
         out = dec(sem_embed_ds, feats, [supp], depth, metas, prev_volumes)
         return self._classify(out['bin_occ'], out['feat_occ'])
