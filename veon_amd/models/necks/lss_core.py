@@ -208,6 +208,32 @@ class LSSCore(_Base):
             bev_feat = torch.cat(bev_feat.unbind(dim=2), 1)
         return bev_feat
 
+    def prepare_lift(self, metas):
+        """Issue the per-call prepare (geometry + counting sort) of the sync-free lift
+        NOW, on the current stream: it depends on the camera tensors only, so a caller
+        that has them early (``VeonOccupancyPath``: before the encoders finish) can
+        take it off the depth -> lift critical path.  ``metas`` = ``input[1:7]`` of the
+        later ``forward`` call -- the SAME tensor objects; the stash is consumed by that
+        call and ignored by any other.  No-op (None) when the lift is not sync-free or
+        the sparse lift needs the depth."""
+        if (self.accelerate or not self.sync_free or getattr(self, 'sparse_depth_eps', None)
+                or not metas[0].is_cuda or torch.is_grad_enabled()):
+            return None
+        sensor2ego, _, cam2imgs, post_rots, post_trans, bda = metas[:6]
+        pre = _prep._HIP_PREPARE.prepare_cameras(
+            self.frustum, sensor2ego, cam2imgs, post_rots, post_trans, bda,
+            self.grid_lower_bound, self.grid_interval, self.grid_size)
+        self.__dict__['_prepared'] = (
+            tuple(id(t) for t in (sensor2ego, cam2imgs, post_rots, post_trans, bda)), pre)
+        return pre
+
+    def _take_prepared(self, sensor2ego, cam2imgs, post_rots, post_trans, bda):
+        st = self.__dict__.pop('_prepared', None)
+        if st is not None and st[0] == tuple(
+                id(t) for t in (sensor2ego, cam2imgs, post_rots, post_trans, bda)):
+            return st[1]
+        return None
+
     def _lift_maxpool(self, input, depth, feat, ds, out_volume=None):
         """forward's pool + (dz,dy,dx) block max in one kernel (inference).
         depth (B,N,D,H,W), feat (B,N,C,H,W) -> (B,C,Z/dz,Y/dy,X/dx), or into
@@ -223,12 +249,14 @@ class LSSCore(_Base):
                 out_volume=out_volume)
         sensor2ego, _, cam2imgs, post_rots, post_trans, bda = input[1:7]
         if self.sync_free:
-            feat, join = self._rows_beside_prepare(feat, depth)
-            pre = _prep._HIP_PREPARE.prepare_cameras(
-                self.frustum, sensor2ego, cam2imgs, post_rots, post_trans, bda,
-                self.grid_lower_bound, self.grid_interval, self.grid_size,
-                **self._sparse_args(depth))
-            join()
+            pre = self._take_prepared(sensor2ego, cam2imgs, post_rots, post_trans, bda)
+            if pre is None:
+                feat, join = self._rows_beside_prepare(feat, depth)
+                pre = _prep._HIP_PREPARE.prepare_cameras(
+                    self.frustum, sensor2ego, cam2imgs, post_rots, post_trans, bda,
+                    self.grid_lower_bound, self.grid_interval, self.grid_size,
+                    **self._sparse_args(depth))
+                join()
             return _bp.bev_pool_v2_maxpool(
                 depth, feat, pre.ranks_depth, pre.ranks_feat, pre.ranks_bev,
                 shape, pre.interval_starts, pre.interval_lengths, ds,

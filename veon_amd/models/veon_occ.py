@@ -167,8 +167,12 @@ class VeonOccupancyPath(nn.Module):
         dec = self.occ_decoder
         hf, wf = self.input_size[0] // 16, self.input_size[1] // 16
 
-        def prep():
-            return None if metas is None else dec.prepare_meta(metas)
+        def prep():   # camera algebra, then the lift's (depth-independent) prepare
+            if metas is None:
+                return None
+            m2 = dec.prepare_meta(metas)
+            self.view_transformer.prepare_lift(m2)
+            return m2
 
         def sem():   # CLIP -> HSA -> CLIP tail, then (fast path) the 2-D fusion layer
             feats, supp = self.clip_features(img)
