@@ -21,6 +21,10 @@ SHAPES = [('B qkv', 5406, 2304, 768), ('B proj', 5406, 768, 768), ('B fc1', 5406
           ('L fc1', 5406, 4096, 1024), ('L fc2', 5406, 1024, 4096),
           ('clipB qkv', 1062, 2304, 768), ('clipB fc1', 1062, 3072, 768),
           ('hsa head', 16896, 384, 384)]
+if os.environ.get('SPLITK_EMU'):   # split-K emulated as more rows with a shorter K
+    SHAPES = [('L fc2 /2', 10812, 1024, 2048), ('L fc2 /4', 21624, 1024, 1024),
+              ('B fc2 /2', 10812, 768, 1536), ('B fc2 /3', 16218, 768, 1024),
+              ('L qkv /2', 10812, 3072, 512), ('B qkv /2', 10812, 2304, 384)]
 NAMES = {0: 'small', 1: '256x256', 2: '192x192', 3: '128x192', 4: '128x256', 5: '256x192',
          6: '128x128', 7: '256x128'}
 NC = len(NAMES)
