@@ -34,10 +34,15 @@ namespace {
 constexpr int kWave = 64;
 
 // Experiment knob of tools/poolbench.py (ablations: bit 0 = workers exit at
-// once, bit 1 = cold workgroups exit at once, bit 2 / 3 = skip warm / hot lists).  0 in production; results are
-// only meaningful with 0.
+// once, bit 1 = cold workgroups exit at once, bit 2 / 3 = skip warm / hot lists;
+// bit 4 = tile = blockIdx instead of the XCD-contiguous order, results unchanged).
+// 0 in production; results of bits 0-3 are only meaningful with 0.
 int g_pool_debug = 0;
 int g_pool_workers = 0, g_pool_cold = 0, g_pool_warm = 0;  // 0 = built-in defaults
+// default tile order (xcd_grouped lg; -1 = blockIdx), from tools/xcd_order_ab.py at SV:
+// fused 165 -> 157 us fp32 rows, 135 -> 128.5 us bf16 rows with runs of 32 tiles; the
+// max-pool kernel (and the S2 slab kernel) gain nothing measurable
+constexpr int kOrderCf = 5, kOrderMp = -1;
 
 inline int launch_status() {
   return hipGetLastError() == hipSuccess ? VEON_OK : VEON_ERR_LAUNCH;
@@ -49,6 +54,28 @@ __device__ __forceinline__ int rl(int v, int lane) {
 __device__ __forceinline__ float rlf(float v, int lane) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
+// Workgroups are dealt to the 8 XCDs round-robin by their linear id, each XCD with
+// its own 4 MiB L2.  The feature row of a pixel is shared by all depth bins of its
+// ray, i.e. by voxels that are neighbours in y (and x).  tile = blockIdx spreads
+// neighbouring tiles over eight L2s; this order hands runs of 2^lg consecutive
+// tiles to ONE XCD (super-groups of 8 * 2^lg tiles permuted among themselves: runs
+// stay short against a z-plane, so the XCDs remain evenly loaded -- one contiguous
+// eighth of the volume per XCD was measured 17 % SLOWER: whole z-planes are empty).
+// Pure scheduling: every tile is still processed once, by one workgroup.
+__device__ __forceinline__ int64_t xcd_grouped(int64_t b, int64_t n, int lg) {
+  if (lg < 0) return b;
+  const int64_t sg = b >> (3 + lg);
+  if (((sg + 1) << (3 + lg)) > n) return b;  // ragged last super-group
+  const int64_t g = (b >> 3) & ((1 << lg) - 1);
+  return (((sg << 3) + (b & 7)) << lg) + g;
+}
+// order knob from the debug flags: bit 4 = identity, bits 8..11 = lg + 1 (0: default)
+inline int tile_order_lg(int flags, int dflt) {
+  if (flags & 16) return -1;
+  const int v = (flags >> 8) & 15;
+  return v ? v - 1 : dflt;
+}
+
 __device__ __forceinline__ int uni(int v) {
   return __builtin_amdgcn_readfirstlane(v);
 }
@@ -371,7 +398,7 @@ __global__ __launch_bounds__(kMW * 64) void k_rows_maxpool(
     const float* __restrict__ depth, const void* __restrict__ feat,
     const int* __restrict__ ranks_depth, const int* __restrict__ ranks_feat,
     const int* __restrict__ vstart, int c, int batch, int Z, int Y, int X,
-    void* __restrict__ outp, int dbg, int kWorkers, int kCold, int kWarm) {
+    void* __restrict__ outp, int dbg, int kWorkers, int kCold, int kWarm, int order) {
   constexpr int NSEG = DZ * DY, GL = DX, NE = NSEG * (GL + 1), FULL = DZ * DY * DX;
   static_assert(NE <= 16, "boundary entries of one pooled voxel must fit 16 lanes");
   if (dbg && (((dbg & 1) && blockIdx.x < kWorkers) || ((dbg & 2) && blockIdx.x >= kWorkers)))
@@ -558,7 +585,10 @@ __global__ __launch_bounds__(kMW * 64) void k_rows_maxpool(
   float* tile = reinterpret_cast<float*>(lds_i);  // OUT == 0: [256][kPV + 1]
   int* hotf = lds_i + 256 * (kPV + 1);            // OUT == 0: [kPV] column is not cold
   const int chunks = (plane + kPV - 1) / kPV;
-  const int64_t cw = (int64_t)blockIdx.x - kWorkers;
+  // cold workgroup -> chunk of pooled voxels in XCD-grouped order (the linear id
+  // of cold workgroup i is kWorkers + i, kWorkers a multiple of 8)
+  const int64_t cw = xcd_grouped((int64_t)blockIdx.x - kWorkers,
+                                 (int64_t)gridDim.x - kWorkers, order);
   const int b = (int)(cw / chunks);
   const int lin0 = (int)(cw - (int64_t)b * chunks) * kPV;
 
@@ -750,7 +780,7 @@ __global__ __launch_bounds__(NW * 64) void k_rows_fused_cf(
     const float* __restrict__ depth, const void* __restrict__ feat,
     const int* __restrict__ ranks_depth, const int* __restrict__ ranks_feat,
     const int* __restrict__ vstart, int c, int64_t vpb, int64_t tiles_per_batch,
-    float* __restrict__ out, int64_t ostride) {
+    float* __restrict__ out, int64_t ostride, int chunked) {
   constexpr int VW = TILE / NW;  // voxels per wave
   constexpr int LDC = TILE + 1;
   constexpr int kShort = kWave / VW;  // the wave's short voxels fit one batch
@@ -759,7 +789,7 @@ __global__ __launch_bounds__(NW * 64) void k_rows_fused_cf(
   int* hlist = reinterpret_cast<int*>(tile + 256 * LDC);       // [TILE][3] col, start, len
   int* hctr = hlist + 3 * TILE;                                // [2] pushed, pulled
   const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x >> 6;
-  const int64_t t = blockIdx.x;
+  const int64_t t = xcd_grouped(blockIdx.x, gridDim.x, chunked);
   const int b = (int)(t / tiles_per_batch);
   const int64_t vox0 = (t - (int64_t)b * tiles_per_batch) * TILE;
   const int64_t rem = vpb - vox0;
@@ -922,7 +952,8 @@ inline bool aligned16(const void* p) {
 
 extern "C" {
 
-void veon_pool_debug_set(int flags) { g_pool_debug = flags; }
+int veon_pool_debug_flags = 0;  // the same flags for bev_pool_v2.hip (bit 4: tile = blockIdx)
+void veon_pool_debug_set(int flags) { g_pool_debug = flags; veon_pool_debug_flags = flags; }
 void veon_pool_tune_set(int workers, int cold_max, int warm_max) {
   g_pool_workers = workers;
   g_pool_cold = cold_max;
@@ -984,7 +1015,8 @@ int veon_bev_pool_v2_fwd_rows(int c, int batch, int64_t voxels_per_batch,
     hipLaunchKernelGGL((k_rows_fused_cf<FT, TILE, NW, HIF>),                    \
                        dim3((unsigned)n_tiles),                                      \
                        dim3(NW * 64), lds, s, depth, feat, ranks_depth, ranks_feat,  \
-                       vstart, c, voxels_per_batch, tpb, out, plane_stride);         \
+                       vstart, c, voxels_per_batch, tpb, out, plane_stride,          \
+                       tile_order_lg(g_pool_debug, kOrderCf));                                 \
   } while (0)
 #define VEON_ROWS_CF_D(FT, TILE, NW)                                  \
   do {                                                                \
@@ -1043,12 +1075,12 @@ int veon_bev_pool_v2_fwd_rows_maxpool(int c, int batch, int Z, int Y, int X, int
       hipLaunchKernelGGL((k_rows_maxpool<FT, 2, 2, 2, 1>), dim3((unsigned)wgs), \
                          dim3(kMW * 64), lds_hot, s, depth, feat, ranks_depth,       \
                          ranks_feat, vstart, c, batch, Z, Y, X, out, g_pool_debug,  \
-                         kWorkers, kCold, kWarm);                                   \
+                         kWorkers, kCold, kWarm, tile_order_lg(g_pool_debug, kOrderMp)); \
     else                                                                            \
       hipLaunchKernelGGL((k_rows_maxpool<FT, 2, 2, 2, 0>), dim3((unsigned)wgs), \
                          dim3(kMW * 64), lds_cf, s, depth, feat, ranks_depth,        \
                          ranks_feat, vstart, c, batch, Z, Y, X, out, g_pool_debug,  \
-                         kWorkers, kCold, kWarm);                                   \
+                         kWorkers, kCold, kWarm, tile_order_lg(g_pool_debug, kOrderMp)); \
   } while (0)
   if (feat_dtype == VEON_FEAT_F32) VEON_ROWS_MP(VEON_FEAT_F32);
   else if (feat_dtype == VEON_FEAT_F16) VEON_ROWS_MP(VEON_FEAT_F16);

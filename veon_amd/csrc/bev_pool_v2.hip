@@ -17,6 +17,8 @@
 
 #include "../../include/veon_hip.h"
 
+extern "C" int veon_pool_debug_flags;  // bev_pool_rows.hip
+
 namespace {
 
 constexpr int kBlock = 256;
@@ -347,7 +349,7 @@ constexpr int kPmax = 1024;  // points staged per window (8 B each)
 template <int VEC, int CAP, typename FT>
 __global__ __launch_bounds__(kBlock) void k_pool_fused_cf(
     PoolArgs a, const int4* __restrict__ plan, int c, int cs, int64_t vpb,
-    int64_t tiles_per_batch, float* __restrict__ out, int64_t ostride) {
+    int64_t tiles_per_batch, float* __restrict__ out, int64_t ostride, int chunked) {
   // ostride: distance between channel planes of `out` in floats (>= vpb; vpb for
   // the contiguous (B,C,Z,Y,X) tensor the reference returns)
   extern __shared__ float lds[];
@@ -364,7 +366,15 @@ __global__ __launch_bounds__(kBlock) void k_pool_fused_cf(
   const int tid = threadIdx.x;
   const int lane = tid & (kWave - 1);
   const int w = tid >> 6;
-  const int64_t t = blockIdx.x;
+  // XCD k (workgroups k, k + 8, ...) takes the k-th contiguous eighth of the tiles:
+  // plan entries, interval starts and ranks of neighbouring tiles share cache
+  // lines, which then live in ONE L2 instead of being fetched by all eight
+  int64_t t = blockIdx.x;
+  if (chunked >= 0) {  // runs of 2^chunked tiles per XCD (bev_pool_rows.hip: xcd_grouped)
+    const int64_t sg = t >> (3 + chunked);
+    if (((sg + 1) << (3 + chunked)) <= (int64_t)gridDim.x)
+      t = (((sg << 3) + (t & 7)) << chunked) + ((t >> 3) & ((1 << chunked) - 1));
+  }
   const int c0 = blockIdx.y * cs;
   const int nch = (c - c0) < cs ? (c - c0) : cs;
   const TileInfo ti = tile_info(t, tiles_per_batch, vpb);
@@ -991,10 +1001,13 @@ static int fused_impl(int c, int n_intervals, int batch, int64_t voxels_per_batc
   const size_t lds = (size_t)cs * (cap + 1) * sizeof(float) +
                      (size_t)(2 * kTileV + 2 + 2 * kPmax) * sizeof(int);
   const dim3 grid((unsigned)n_tiles, (unsigned)slabs);
+  // (with several channel slabs the linear workgroup id is not the tile id)
+  const int ov = (veon_pool_debug_flags >> 8) & 15;
+  const int chunked = (slabs != 1 || (veon_pool_debug_flags & 16)) ? -1 : (ov ? ov - 1 : -1);
 #define VEON_LAUNCH_CF(VEC, CAP, FT)                                          \
   hipLaunchKernelGGL((k_pool_fused_cf<VEC, CAP, FT>), grid, dim3(kBlock), lds, \
                      s, a, plan4, c, cs, voxels_per_batch, tiles_per_batch, out,   \
-                     plane_stride)
+                     plane_stride, chunked)
 #define VEON_LAUNCH_CF2(VEC, FT) \
   do { if (dense) VEON_LAUNCH_CF(VEC, 64, FT); else VEON_LAUNCH_CF(VEC, 32, FT); } while (0)
   if (feat_dtype == VEON_FEAT_F32) {
