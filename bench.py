@@ -25,6 +25,8 @@ also carries
   `veonb` BASELINE configs[2]: the whole 3-D occupancy path (DA-V2 ViT-B + CLIP
           ViT-B/16 + HSA + lift + Conv3d body + heads), ms per 6-camera sample and
           the MFMA roofline of its conv body;
+  `veonl_fp16` BASELINE configs[4] on one GPU: the VEON-L path with fp16 operands
+          (libveon_hip_f16.so), whole forward from one hipGraph;
   `cpu_baseline` the pure-PyTorch index_add_ port of the step on the host cores,
           at the best of several thread counts.
 """
@@ -76,6 +78,12 @@ def parse():
     p.add_argument('--cpu-seconds', type=float, default=10.0)
     p.add_argument('--no-sv', action='store_true', help='skip the `sv` sub-object')
     p.add_argument('--no-veonb', action='store_true', help='skip the `veonb` sub-object')
+    p.add_argument('--no-veonl', action='store_true', help='skip the `veonl_fp16` sub-object')
+    p.add_argument('--half', default=os.environ.get('VEON_HALF', 'bf16'),
+                   choices=['bf16', 'fp16'],
+                   help='16-bit operand type of the MFMA path for --workload VEONB / VEONL '
+                        '(veon_amd/half.py: libveon_hip.so / libveon_hip_f16.so); BASELINE '
+                        'configs[2] names bf16, configs[4] fp16')
     p.add_argument('--no-pmc', action='store_true',
                    help='skip the rocprofv3 --pmc child passes (roofline.traffic = null)')
     return p.parse_args()
@@ -257,8 +265,8 @@ VEON_WHAT = ('the 3-D occupancy path of VeonTemporal.simple_test '
              'blocks -> HSA network -> CLIP tail with attention biases; CatFusionLift -> '
              'sync-free lift (D=88, C=256, 200x200x16, fused 2x2x2 max-pool) -> 4x '
              'ResBlock3D -> occ/sem heads -> open-vocab classifier -> upsample -> arg-max; '
-             'bf16 on MFMA, random weights; timm side-adapter ViT / mask decoder / text '
-             'encoder not included')
+             '%s operands on MFMA (fp32 accumulation), random weights; timm side-adapter ViT '
+             '/ mask decoder / text encoder not included')
 
 
 def bench_hotpath(args, rank, world, dev, dist):
@@ -266,6 +274,8 @@ def bench_hotpath(args, rank, world, dev, dist):
     (default): one sample per GPU, no collective (BASELINE configs[4]); --shard
     cameras: the six cameras of ONE sample over the ranks, encoders per shard, one
     RCCL all-reduce of the voxel feature volume (configs[3])."""
+    from veon_amd import half
+    half.set_half_dtype(args.half)   # before any module packs its weights
     enc = 'vitb' if args.workload == 'VEONB' else 'vitl'
     clip = 'ViT-B/16' if enc == 'vitb' else 'ViT-L/14-336'
     if args.shard == 'cameras':
@@ -295,9 +305,10 @@ def bench_hotpath(args, rank, world, dev, dist):
         'metric': '6cam_hotpath_samples_per_sec', 'value': round(value, 2),
         'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(ms, 4), 'higher_is_better': True, 'scaling': scaling,
-        'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+        'vs_baseline': None, 'dtype': half.name(), 'data': 'synthetic',
         'config': {'workload': '%s, 6-cam 256x704: ' % args.workload +
-                               VEON_WHAT % ('ViT-B' if enc == 'vitb' else 'ViT-L', clip),
+                               VEON_WHAT % ('ViT-B' if enc == 'vitb' else 'ViT-L', clip,
+                                            half.name()),
                    'parallelism': par, 'launch': launch, 'stages_ms': stages},
         'roofline': {'kernel': 'k_conv3d_k3 (8 launches, AlignNetOcc3D body)', 'bound': 'mfma',
                      'achieved': round(tf, 1), 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
@@ -557,7 +568,7 @@ def main():
             ms, stages, tf, launch = veon_path(args, dev, 'vitb', (256, 704), 20, 3, None, 1)
             result['veonb'] = {
                 'workload': 'VEONB (BASELINE configs[2]), 6-cam 256x704: ' +
-                            VEON_WHAT % ('ViT-B', 'ViT-B/16'),
+                            VEON_WHAT % ('ViT-B', 'ViT-B/16', 'bf16'),
                 'ms_per_step': round(ms, 4), 'samples_per_s': round(1e3 / ms, 2),
                 'steps': 20, 'dtype': 'bf16', 'launch': launch, 'stages_ms': stages,
                 'roofline': {'kernel': 'k_conv3d_k3 (8 launches, AlignNetOcc3D body)',
@@ -566,6 +577,25 @@ def main():
                              'frac': round(tf / MFMA_PEAK_TFLOPS, 4)}}
         except Exception as e:  # report, do not hide
             print('veonb sub-object failed: %r' % (e,), file=sys.stderr)
+    if solo and not args.no_veonl and args.workload == 'S2':
+        # BASELINE configs[4] on one GPU: VEON-L, fp16 operands, hipGraph-captured
+        # forward (8 x data-parallel = 8 such replicas, no collective)
+        try:
+            from veon_amd import half
+            torch.cuda.empty_cache()
+            with half.use('fp16'):
+                ms, stages, tf, launch = veon_path(args, dev, 'vitl', (256, 704), 10, 2, None, 1)
+            result['veonl_fp16'] = {
+                'workload': 'VEONL (BASELINE configs[4], one replica), 6-cam 256x704: ' +
+                            VEON_WHAT % ('ViT-L', 'ViT-L/14-336', 'fp16'),
+                'ms_per_step': round(ms, 4), 'samples_per_s': round(1e3 / ms, 2),
+                'steps': 10, 'dtype': 'fp16', 'launch': launch, 'stages_ms': stages,
+                'roofline': {'kernel': 'k_conv3d_k3 (8 launches, AlignNetOcc3D body)',
+                             'bound': 'mfma', 'achieved': round(tf, 1),
+                             'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                             'frac': round(tf / MFMA_PEAK_TFLOPS, 4)}}
+        except Exception as e:  # report, do not hide
+            print('veonl_fp16 sub-object failed: %r' % (e,), file=sys.stderr)
     if solo and not args.no_cpu_baseline:
         result['cpu_baseline'] = cpu_baseline(args, grid, input_size, n_cams, C,
                                               rig, depth5, feat5)

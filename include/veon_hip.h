@@ -42,6 +42,11 @@ extern "C" {
 #define VEON_FEAT_BF16 2
 
 int veon_abi_version(void);
+/* 16-bit operand type this build of the library was compiled for: 0 = bf16
+ * (libveon_hip.so), 1 = IEEE fp16 (libveon_hip_f16.so: the same sources with
+ * -DVEON_HALF_FP16).  Every entry point named *_bf16 and every "bf16" buffer in
+ * this header means "the half type of the build"; accumulation is fp32 in both. */
+int veon_half_mode(void);
 const char *veon_status_string(int status);
 
 /*

@@ -1,0 +1,175 @@
+"""The fp16 flavour of the MFMA path (libveon_hip_f16.so, veon_amd/half.py; BASELINE
+configs[4] "VEON-L fp16") against plain PyTorch fp32 references of the same ops on
+the same fp16-rounded operands, and against the reference-chained path vector at a
+STATED FP16 TOLERANCE.  fp16 outputs carry a half-ulp of 2^-12 relative (bf16:
+2^-9), so the per-op tolerances here are 8x tighter than in test_vit_ops_gpu.py /
+test_conv3d_gpu.py, and the path tolerance is tighter than the bf16 one of
+test_path_golden.py."""
+import pytest
+import torch
+
+from veon_amd import half
+from tests.conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+F16 = torch.float16
+
+
+@pytest.fixture(autouse=True)
+def _fp16_flavour():
+    with half.use(F16):
+        yield
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(DEV)
+
+
+def test_flavour_switches_library_and_dtype():
+    from veon_amd import _lib, vit_ops
+    assert half.dtype() == F16 and half.name() == 'fp16'
+    assert _lib.lib() is _lib._libs['fp16']
+    x = _rand(257, 33, seed=1, scale=100.0)
+    got = vit_ops.to_bf16(x)            # "to the half type of the build"
+    assert got.dtype == F16 and torch.equal(got, x.to(F16))   # round to nearest even
+    with half.use('bf16'):
+        assert _lib.lib() is _lib._libs['bf16'] and _lib.lib() is not _lib._libs['fp16']
+        assert torch.equal(vit_ops.to_bf16(x), x.to(torch.bfloat16))
+        with pytest.raises(AssertionError):      # operands of the other flavour: loud
+            vit_ops.linear(got, got, None)
+
+
+@pytest.mark.parametrize('T,d', [(901, 768), (17, 1024), (5, 384)])
+def test_layernorm_fp16(T, d):
+    from veon_amd import vit_ops
+    x = _rand(T, d, seed=2, scale=3.0) + 0.5
+    w = _rand(d, seed=3) * 0.1 + 1.0
+    b = _rand(d, seed=4) * 0.1
+    got = vit_ops.layernorm(x, w, b, eps=1e-6)
+    assert got.dtype == F16
+    ref = torch.nn.functional.layer_norm(x, (d,), w, b, 1e-6)
+    torch.testing.assert_close(got.float(), ref, rtol=2 ** -11, atol=3e-4)
+
+
+@pytest.mark.parametrize('M,N,K', [(901, 768, 768), (5406, 2304, 768), (130, 3072, 768),
+                                   (64, 128, 64), (1, 4, 64), (300, 1024, 4096),
+                                   (5406, 768, 3072)])
+def test_gemm_fp16(M, N, K):
+    """small-tile and DMA-ring GEMM kernels on v_mfma_f32_16x16x32_f16."""
+    from veon_amd import vit_ops
+    a = _rand(M, K, seed=5).to(F16)
+    w = (_rand(N, K, seed=6) * K ** -0.5).to(F16)
+    bias = _rand(N, seed=7)
+    ref = a.float() @ w.float().t() + bias
+    got = vit_ops.linear(a, w, bias)
+    assert got.dtype == F16
+    # products exact, fp32 accumulation; the output rounding is 2^-12 relative
+    torch.testing.assert_close(got.float(), ref, rtol=2 ** -11, atol=3e-4)
+    got = vit_ops.linear(a, w, bias, vit_ops.EPI_GELU).float()
+    torch.testing.assert_close(got, torch.nn.functional.gelu(ref), rtol=2 ** -11, atol=3e-4)
+    x = _rand(M, N, seed=15)
+    got = vit_ops.linear_residual_(x.clone(), a, w, bias, None)
+    torch.testing.assert_close(got, x + ref, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize('B,T,H', [(2, 901, 12), (1, 705, 16), (3, 50, 2)])
+def test_attention_fp16(B, T, H):
+    from veon_amd import vit_ops
+    hd = 64
+    qkv = (_rand(B, T, 3 * H * hd, seed=20) * 0.5).to(F16)
+    got = vit_ops.attention(qkv, H)
+    assert got.dtype == F16
+    q, k, v = qkv.float().view(B, T, 3, H, hd).permute(2, 0, 3, 1, 4)
+    ref = torch.softmax(q @ k.transpose(-1, -2), -1) @ v     # q is pre-scaled
+    ref = ref.permute(0, 2, 1, 3).reshape(B, T, H * hd)
+    # P is rounded to fp16 before the PV product: 2^-12 relative per weight
+    torch.testing.assert_close(got.float(), ref, rtol=2e-3, atol=1e-3)
+
+
+@pytest.mark.parametrize('C,Co,Z,Y,X', [(256, 256, 4, 10, 12), (64, 136, 2, 9, 7)])
+def test_conv3d_fp16(C, Co, Z, Y, X):
+    from veon_amd import conv3d_ops
+    x = _rand(1, C, Z, Y, X, seed=30).to(F16).float()
+    w = (_rand(Co, C, 3, 3, 3, seed=31) * (27 * C) ** -0.5).to(F16).float()
+    scale = _rand(Co, seed=32) * 0.1 + 1.0
+    shift = _rand(Co, seed=33) * 0.1
+    vin = conv3d_ops.pack(x)
+    assert vin.rows.dtype == F16 and torch.equal(conv3d_ops.unpack(vin), x)
+    out = conv3d_ops.conv3d_k3(vin, conv3d_ops.pack_weight(w), scale, shift, relu=True)
+    got = conv3d_ops.unpack(out)
+    ref = torch.nn.functional.conv3d(x.double(), w.double(), padding=1).float()
+    ref = torch.relu(ref * scale.view(1, -1, 1, 1, 1) + shift.view(1, -1, 1, 1, 1))
+    torch.testing.assert_close(got, ref, rtol=2 ** -10, atol=1e-3)
+
+
+def test_pool_maxpool_into_padded_fp16_volume():
+    """fused pool + 2x2x2 max-pool writing the Conv3d body's padded input: the fp16
+    build rounds the SAME fp32 maxima to fp16 (bit-equal to .to(float16))."""
+    from tools._inputs import lift_case
+    from veon_amd import conv3d_ops
+    from veon_amd.ops.bev_pool_v2 import bev_pool as bp
+    grid = {'x': [-10.0, 10.0, 0.5], 'y': [-10.0, 10.0, 0.5], 'z': [-1.0, 3.0, 0.5],
+            'depth': [1.0, 13.0, 0.5]}
+    cs = lift_case(grid, (64, 176), 2, 128, DEV)
+    X, Y, Z = cs['gsize']
+    C = 128
+    shape = (1, Z, Y, X, C)
+    vs = bp.build_voxel_table(cs['rb'], cs['st'], 1, Z * Y * X, attach=False)
+    fh = cs['feat_nhwc'].to(F16)
+    ref = bp.rows_maxpool(cs['depth'], fh, cs['rd'], cs['rf'], vs, shape, (2, 2, 2))
+    vol = conv3d_ops.PaddedVolume(1, C, Z // 2, Y // 2, X // 2, torch.device(DEV))
+    bp.rows_maxpool(cs['depth'], fh, cs['rd'], cs['rf'], vs, shape, (2, 2, 2), out_volume=vol)
+    assert vol.rows.dtype == F16
+    assert torch.equal(vol.interior().permute(0, 4, 1, 2, 3), ref.to(F16))
+
+
+def test_native_path_logits_match_reference_chain_fp16():
+    """BASELINE.json: "voxel logits matching the reference within a stated fp16
+    tolerance".  Native path with fp16 operands on MFMA (fp32 accumulation, HIP lift
+    with the fused max-pool) against the fp32 logits of the chain of the reference's
+    own modules (tests/golden/path_tiny.npz): relative L2 <= 1e-2, max |diff| <= 2e-2
+    of the logit range, arg-max agreement >= 99 % (bf16 flavour: 4e-2 / 8e-2 / 97 %,
+    tests/test_path_golden.py)."""
+    from tests.test_path_golden import _build, _inputs
+    g = load_golden('path_tiny')
+    net = _build(g, DEV, native=True)
+    images, geom, metric = _inputs(g, DEV)
+    with torch.no_grad():
+        out = net(images, geom, depth=metric)
+    for k in ('sem_occ', 'bin_occ'):
+        ref = torch.from_numpy(g[k]).to(DEV)
+        got = out[k].float()
+        rel = ((got - ref).norm() / ref.norm()).item()
+        mx = ((got - ref).abs().max() / (ref.max() - ref.min())).item()
+        print('fp16 path %s: rel L2 %.3e, max/range %.3e' % (k, rel, mx))
+        assert rel <= 1e-2 and mx <= 2e-2, (k, rel, mx)
+    ref_cls = torch.from_numpy(g['sem_occ']).to(DEV).argmax(1)
+    agree = (out['sem_occ'].argmax(1) == ref_cls).float().mean().item()
+    assert agree >= 0.99, agree
+
+
+def test_veon_l_preset_fp16_graph_replay():
+    """VEON-L wiring (CLIP ViT-L/14-336 + DA-V2 ViT-L) in the fp16 flavour, two
+    cameras at tiny resolution, eager and replayed from one hipGraph."""
+    from veon_amd import synthetic
+    from veon_amd.graphs import GraphedCallable
+    from veon_amd.models.veon_occ import VeonOccupancyPath
+    torch.manual_seed(0)
+    grid = {'x': [-10.0, 10.0, 1.0], 'y': [-10.0, 10.0, 1.0], 'z': [-1.0, 3.0, 1.0],
+            'depth': [1.0, 13.0, 1.0]}
+    size, ncam = (64, 176), 2
+    net = VeonOccupancyPath(input_size=size, num_cam=ncam, occ_size=(4, 20, 20),
+                            grid_config=grid, embed_dim=64,
+                            **VeonOccupancyPath.VEON_L).to(DEV).eval()
+    geom = [t.to(DEV) for t in synthetic.rig_inputs(synthetic.make_rig(1, ncam, size))]
+    images = torch.randn(1, ncam, 3, *size, device=DEV)
+    with torch.no_grad():
+        want = {k: v.clone() for k, v in net(images, geom).items()}
+        assert all(torch.isfinite(v.float()).all() for v in want.values())
+        graphed = GraphedCallable(lambda im: net(im, geom), (images,))
+        got = graphed(images)
+    for k in ('sem_occ', 'bin_occ'):
+        err = (got[k].float() - want[k].float()).abs().max().item()
+        assert err <= 5e-3 * max(1.0, want[k].abs().max().item()), (k, err)

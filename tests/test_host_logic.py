@@ -36,15 +36,30 @@ def _header_symbols():
 def test_library_exports_every_declared_symbol():
     from veon_amd import build
     build.build()
-    lib = ctypes.CDLL(_lib.LIB_PATH)
     declared = _header_symbols()
     assert declared, 'no declarations found in include/*.h'
-    for name in declared:
-        assert hasattr(lib, name), 'libveon_hip.so lacks %s' % name
     # the Python binding knows every declared entry point and nothing else
     assert set(_lib.declared_symbols()) == declared
-    lib.veon_abi_version.restype = ctypes.c_int
-    assert lib.veon_abi_version() == 1          # host-only call, no GPU needed
+    # both flavours of the library (bf16 / fp16 operands) export all of them
+    for flavour, path in _lib.LIB_PATHS.items():
+        lib = ctypes.CDLL(path)
+        for name in declared:
+            assert hasattr(lib, name), '%s lacks %s' % (os.path.basename(path), name)
+        lib.veon_abi_version.restype = ctypes.c_int
+        assert lib.veon_abi_version() == 1          # host-only calls, no GPU needed
+        assert lib.veon_half_mode() == (1 if flavour == 'fp16' else 0)
+
+
+def test_half_flavour_switch():
+    from veon_amd import half
+    assert half.dtype() == torch.bfloat16 and half.name() == 'bf16'   # default
+    with half.use('fp16'):
+        assert half.dtype() == torch.float16 and half.is_half(torch.float16)
+        assert not half.is_half(torch.bfloat16) and not half.is_half(None)
+        assert _lib.lib().veon_half_mode() == 1
+    assert half.dtype() == torch.bfloat16 and _lib.lib().veon_half_mode() == 0
+    with pytest.raises(ValueError):
+        half.set_half_dtype(torch.float32)
 
 
 def test_ops_refuse_cpu_tensors():

@@ -11,8 +11,12 @@ import os
 
 import torch
 
+from . import half as _half
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libveon_hip.so')
+LIB_PATHS = {'bf16': LIB_PATH, 'fp16': os.path.join(_HERE, 'libveon_hip_f16.so')}
+_libs = {}  # flavour -> loaded library
 _lib = None
 
 _vp = ctypes.c_void_p
@@ -38,6 +42,7 @@ class VitBlockWeights(ctypes.Structure):
 
 _SIGNATURES = {
     'veon_abi_version': (_ci, []),
+    'veon_half_mode': (_ci, []),
     'veon_status_string': (ctypes.c_char_p, [_ci]),
     'veon_bev_pool_v2_fwd': (_ci, [_ci, _ci] + [_vp] * 8 + [_vp]),
     'veon_bev_pool_v2_bwd': (_ci, [_ci, _ci] + [_vp] * 10 + [_vp]),
@@ -121,24 +126,33 @@ def declared_symbols():
 
 def register(name, restype, argtypes):
     _SIGNATURES[name] = (restype, argtypes)
-    if _lib is not None:
-        fn = getattr(_lib, name)
+    for loaded in _libs.values():
+        fn = getattr(loaded, name)
         fn.restype, fn.argtypes = restype, argtypes
 
 
 def lib():
-    """Load libveon_hip.so; raise (never fall back) when it is absent."""
+    """The native library of the process's half flavour (veon_amd/half.py):
+    libveon_hip.so (bf16 operands) or libveon_hip_f16.so (fp16), the same entry
+    points in both; raise (never fall back) when it is absent."""
     global _lib
-    if _lib is None:
-        if not os.path.exists(LIB_PATH):
+    flavour = _half.name()
+    loaded = _libs.get(flavour)
+    if loaded is None:
+        path = LIB_PATHS[flavour]
+        if not os.path.exists(path):
             raise VeonHipError(
                 'veon_amd: %s not found -- build it with `python -m veon_amd.build` '
-                '(hipcc --offload-arch=gfx950). There is no CPU fallback.' % LIB_PATH)
-        _lib = ctypes.CDLL(LIB_PATH)
+                '(hipcc --offload-arch=gfx950). There is no CPU fallback.' % path)
+        loaded = ctypes.CDLL(path)
         for name, (restype, argtypes) in _SIGNATURES.items():
-            fn = getattr(_lib, name)
+            fn = getattr(loaded, name)
             fn.restype, fn.argtypes = restype, argtypes
-    return _lib
+        if loaded.veon_half_mode() != (1 if flavour == 'fp16' else 0):
+            raise VeonHipError('%s was not built for %s operands' % (path, flavour))
+        _libs[flavour] = loaded
+    _lib = loaded
+    return loaded
 
 
 # number of native calls per entry point (every call ends in check()); the GPU

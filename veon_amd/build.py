@@ -15,6 +15,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 INCLUDE = os.path.join(os.path.dirname(HERE), 'include')
 LIB = os.path.join(HERE, 'libveon_hip.so')
+# the same sources with -DVEON_HALF_FP16: IEEE fp16 operands on the MFMA kernels
+# instead of bf16 (csrc/mfma_common.h); selected by veon_amd.half.set_half_dtype
+LIB_F16 = os.path.join(HERE, 'libveon_hip_f16.so')
+FLAVOURS = {'bf16': (LIB, '_build', []), 'fp16': (LIB_F16, '_build_f16', ['-DVEON_HALF_FP16'])}
 ARCH = 'gfx950'
 
 # -ffp-contract=off: the only fused multiply-adds are the explicit fmaf() calls,
@@ -32,11 +36,15 @@ def _deps():
         glob.glob(os.path.join(INCLUDE, '*.h'))
 
 
-def up_to_date():
-    if not os.path.exists(LIB):
-        return False
-    t = os.path.getmtime(LIB)
-    return all(os.path.getmtime(d) <= t for d in _deps())
+def up_to_date(flavour=None):
+    for fl in ([flavour] if flavour else list(FLAVOURS)):
+        lib = FLAVOURS[fl][0]
+        if not os.path.exists(lib):
+            return False
+        t = os.path.getmtime(lib)
+        if not all(os.path.getmtime(d) <= t for d in _deps()):
+            return False
+    return True
 
 
 def hipcc():
@@ -47,8 +55,8 @@ def hipcc():
     return 'hipcc'
 
 
-def _obj(src):
-    return os.path.join(HERE, '_build', os.path.basename(src)[:-4] + '.o')
+def _obj(src, flavour='bf16'):
+    return os.path.join(HERE, FLAVOURS[flavour][1], os.path.basename(src)[:-4] + '.o')
 
 
 def _stale(obj, src):
@@ -60,20 +68,24 @@ def _stale(obj, src):
 
 
 def build(force=False, verbose=False, jobs=None):
-    """One object per .hip (compiled in parallel, only the stale ones), then one
-    link: an edit of one kernel file rebuilds in seconds."""
+    """One object per .hip and flavour (compiled in parallel, only the stale ones),
+    then one link per flavour: an edit of one kernel file rebuilds in seconds.
+    Returns the path of the default (bf16) library."""
     if not force and up_to_date():
         return LIB
-    os.makedirs(os.path.join(HERE, '_build'), exist_ok=True)
     cflags = [f for f in FLAGS if f != '-shared']
-    todo = [s for s in sources() if force or _stale(_obj(s), s)]
+    todo = []
+    for fl, (lib, objdir, defs) in FLAVOURS.items():
+        os.makedirs(os.path.join(HERE, objdir), exist_ok=True)
+        todo += [(s, fl) for s in sources() if force or _stale(_obj(s, fl), s)]
     jobs = jobs or min(len(todo), max(1, (os.cpu_count() or 2) // 2)) or 1
     procs, failed = [], False
     pending = list(todo)
     while pending or procs:
         while pending and len(procs) < jobs:
-            src = pending.pop(0)
-            cmd = [hipcc()] + cflags + ['-I', INCLUDE, '-c', src, '-o', _obj(src)]
+            src, fl = pending.pop(0)
+            cmd = [hipcc()] + cflags + FLAVOURS[fl][2] + ['-I', INCLUDE, '-c', src, '-o',
+                                                          _obj(src, fl)]
             if verbose:
                 print(' '.join(cmd))
             procs.append((src, subprocess.Popen(cmd)))
@@ -83,11 +95,12 @@ def build(force=False, verbose=False, jobs=None):
             print('hipcc failed on', src, file=sys.stderr)
     if failed:
         raise subprocess.CalledProcessError(1, 'hipcc')
-    cmd = [hipcc(), '-shared', '-fPIC', '--offload-arch=' + ARCH, '-o', LIB] + \
-        [_obj(s) for s in sources()]
-    if verbose:
-        print(' '.join(cmd))
-    subprocess.check_call(cmd)
+    for fl, (lib, objdir, defs) in FLAVOURS.items():
+        cmd = [hipcc(), '-shared', '-fPIC', '--offload-arch=' + ARCH, '-o', lib] + \
+            [_obj(s, fl) for s in sources()]
+        if verbose:
+            print(' '.join(cmd))
+        subprocess.check_call(cmd)
     return LIB
 
 

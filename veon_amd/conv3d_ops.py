@@ -8,6 +8,7 @@ stream; there is no CPU path.
 import torch
 
 from . import _lib
+from . import half as _half
 
 
 class PaddedVolume:
@@ -21,7 +22,7 @@ class PaddedVolume:
         self.guard = int(_lib.lib().veon_conv3d_guard_rows(Y, X))
         self.M = B * (Z + 2) * (Y + 2) * (X + 2)
         self.storage = torch.zeros((self.M + 2 * self.guard, C),
-                                   dtype=torch.bfloat16, device=device)
+                                   dtype=_half.dtype(), device=device)
         self.rows = self.storage[self.guard:self.guard + self.M]
 
     @property
@@ -69,7 +70,7 @@ def unpack(vol, out=None):
 def pack_weight(w):
     """nn.Conv3d weight (Cout,Cin,3,3,3) -> bf16 [Cout][3][3][3][Cin]."""
     assert w.dim() == 5 and tuple(w.shape[2:]) == (3, 3, 3)
-    return w.detach().permute(0, 2, 3, 4, 1).contiguous().to(torch.bfloat16)
+    return w.detach().permute(0, 2, 3, 4, 1).contiguous().to(_half.dtype())
 
 
 def conv3d_k3(vol, w_packed, scale=None, shift=None, resid=None, relu=False,
@@ -80,7 +81,7 @@ def conv3d_k3(vol, w_packed, scale=None, shift=None, resid=None, relu=False,
     dev = _lib.require_device(vol.storage, w_packed)
     B, Cin, Z, Y, X = vol.shape
     Cout = w_packed.shape[0]
-    assert w_packed.dtype == torch.bfloat16 and w_packed.is_contiguous()
+    assert w_packed.dtype == _half.dtype() and w_packed.is_contiguous()
     assert w_packed.numel() == Cout * 27 * Cin
     if out is None:
         out = vol.like(Cout)
@@ -180,7 +181,7 @@ class PaddedImage:
         self.guard = int(_lib.lib().veon_conv3d_guard_rows(Y, X))
         self.M = B * (Y + 2) * (X + 2)
         self.storage = torch.zeros((self.M + 2 * self.guard, C),
-                                   dtype=torch.bfloat16, device=device)
+                                   dtype=_half.dtype(), device=device)
         self.rows = self.storage[self.guard:self.guard + self.M]
 
     @property
@@ -191,7 +192,7 @@ class PaddedImage:
 def pack_image(x, out=None):
     """(B,C,H,W) fp32 or bf16 -> PaddedImage."""
     dev = _lib.require_device(x)
-    if x.dtype not in (torch.float32, torch.bfloat16):
+    if x.dtype not in (torch.float32, _half.dtype()):
         x = x.float()
     B, C, Y, X = x.shape
     if out is None:
@@ -205,7 +206,7 @@ def pack_image(x, out=None):
     x = x.contiguous()
     with torch.cuda.device(dev):
         st = _lib.lib().veon_image_pack_bf16(
-            _lib.ptr(x), 1 if x.dtype == torch.bfloat16 else 0, _lib.ptr(out.rows),
+            _lib.ptr(x), 1 if x.dtype == _half.dtype() else 0, _lib.ptr(out.rows),
             B, C, Y, X, _lib.stream_ptr(dev))
     _lib.check(st, 'veon_image_pack_bf16')
     return out
@@ -218,7 +219,7 @@ def unpack_image(img, dtype=torch.float32, channels=None):
     out = torch.empty(img.shape, dtype=dtype, device=dev)
     with torch.cuda.device(dev):
         st = _lib.lib().veon_image_unpack(
-            _lib.ptr(img.rows), _lib.ptr(out), 1 if dtype == torch.bfloat16 else 0,
+            _lib.ptr(img.rows), _lib.ptr(out), 1 if dtype == _half.dtype() else 0,
             B, C, Y, X, _lib.stream_ptr(dev))
     _lib.check(st, 'veon_image_unpack')
     return out if channels is None else out[:, :channels]
@@ -232,7 +233,7 @@ def pack_weight2d(w, pad_out_to=8):
     npad = (cout + pad_out_to - 1) // pad_out_to * pad_out_to
     wp = torch.zeros((npad,) + tuple(w.shape[1:]), dtype=torch.float32, device=w.device)
     wp[:cout] = w.detach().float()
-    return wp.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16)
+    return wp.permute(0, 2, 3, 1).contiguous().to(_half.dtype())
 
 
 _ACT = {None: 0, 'none': 0, 'relu': 1, 'gelu': 2}
@@ -246,7 +247,7 @@ def conv2d_k3(img, w_packed, scale=None, shift=None, resid=None, relu=False,
     dev = _lib.require_device(img.storage, w_packed)
     B, Cin, Y, X = img.shape
     Cout = w_packed.shape[0]
-    assert w_packed.dtype == torch.bfloat16 and w_packed.is_contiguous()
+    assert w_packed.dtype == _half.dtype() and w_packed.is_contiguous()
     assert w_packed.numel() == Cout * 9 * Cin
     if out is None:
         out = PaddedImage(B, Cout, Y, X, dev)
@@ -268,7 +269,7 @@ def conv2d_k3s2(img, w_packed, scale=None, shift=None, out=None, act=None):
     dev = _lib.require_device(img.storage, w_packed)
     B, Cin, Y, X = img.shape
     Cout = w_packed.shape[0]
-    assert w_packed.dtype == torch.bfloat16 and w_packed.is_contiguous()
+    assert w_packed.dtype == _half.dtype() and w_packed.is_contiguous()
     assert w_packed.numel() == Cout * 9 * Cin
     Yo, Xo = (Y + 1) // 2, (X + 1) // 2
     if out is None:
@@ -349,7 +350,7 @@ def tokens_to_image(rows, tokens_per_image, skip, h, w, s, C, out):
     of every image (class token) are passed over."""
     dev = _lib.require_device(rows, out.storage)
     B = out.shape[0]
-    assert rows.dtype == torch.bfloat16 and rows.is_contiguous() and rows.dim() == 2
+    assert rows.dtype == _half.dtype() and rows.is_contiguous() and rows.dim() == 2
     assert out.shape == (B, C, s * h, s * w) and rows.shape[0] == B * tokens_per_image
     with _lib.on_device(dev):
         st = _lib.lib().veon_tokens_to_image(

@@ -28,6 +28,7 @@
 #include <stdint.h>
 
 #include "../../include/veon_hip.h"
+#include "half_mode.h"
 
 namespace {
 
@@ -380,10 +381,10 @@ __device__ __forceinline__ int64_t seg_entry(int b, int zo, int yo, int xo, int 
 
 __device__ __forceinline__ uint2 pack_bf16x4(const float* v) {
   uint2 pk;
-  pk.x = (unsigned)__builtin_bit_cast(unsigned short, (__bf16)v[0]) |
-         ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)v[1]) << 16);
-  pk.y = (unsigned)__builtin_bit_cast(unsigned short, (__bf16)v[2]) |
-         ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)v[3]) << 16);
+  pk.x = (unsigned)__builtin_bit_cast(unsigned short, (veon_half_native)v[0]) |
+         ((unsigned)__builtin_bit_cast(unsigned short, (veon_half_native)v[1]) << 16);
+  pk.y = (unsigned)__builtin_bit_cast(unsigned short, (veon_half_native)v[2]) |
+         ((unsigned)__builtin_bit_cast(unsigned short, (veon_half_native)v[3]) << 16);
   return pk;
 }
 
@@ -507,7 +508,7 @@ __global__ __launch_bounds__(kMW * 64) void k_rows_maxpool(
               }
             const float v = pooled_value(m, n_occ, FULL);
             if constexpr (OUT == 1)
-              out_row(b, lin)[c0 + cc] = __builtin_bit_cast(unsigned short, (__bf16)v);
+              out_row(b, lin)[c0 + cc] = __builtin_bit_cast(unsigned short, (veon_half_native)v);
             else
               static_cast<float*>(outp)[((int64_t)b * c + c0 + cc) * plane + lin] = v;
           }

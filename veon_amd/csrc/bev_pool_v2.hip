@@ -16,6 +16,7 @@
 #include <stdint.h>
 
 #include "../../include/veon_hip.h"
+#include "half_mode.h"
 
 extern "C" int veon_pool_debug_flags;  // bev_pool_rows.hip
 
@@ -596,7 +597,7 @@ __global__ __launch_bounds__(kBlock) void k_pool_maxpool_cf(
         v = key_float(tile[cc * Xo + xo]);
         if (n < full && !(v > 0.f)) v = 0.f;
       }
-      ob[(int64_t)xo * c + cc] = __builtin_bit_cast(unsigned short, (__bf16)v);
+      ob[(int64_t)xo * c + cc] = __builtin_bit_cast(unsigned short, (veon_half_native)v);
     }
     return;
   }
@@ -703,6 +704,7 @@ __global__ __launch_bounds__(256) void k_feat_nchw_to_nhwc(const T* __restrict__
 extern "C" {
 
 int veon_abi_version(void) { return VEON_ABI_VERSION; }
+int veon_half_mode(void) { return VEON_HALF_MODE; }
 
 const char* veon_status_string(int status) {
   switch (status) {

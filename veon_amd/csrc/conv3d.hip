@@ -180,8 +180,8 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv3d_k3(
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           // acc[i][j][reg] = C[voxel i*16 + fr][feature j*16 + 4*fg + reg]
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i],
-                                                               acc[i][j], 0, 0, 0);
+          acc[i][j] = mfma_16x16x32(fw[j], fa[i],
+                                                               acc[i][j]);
     }
   };
   dma(0, 0);
@@ -383,8 +383,8 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv3d_k3_ax(
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           // acc[i][j][reg] = C[voxel i*16 + fr][feature j*16 + 4*fg + reg]
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i],
-                                                               acc[i][j], 0, 0, 0);
+          acc[i][j] = mfma_16x16x32(fw[j], fa[i],
+                                                               acc[i][j]);
     }
   };
   dma_a(0);

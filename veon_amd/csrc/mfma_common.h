@@ -21,6 +21,32 @@ typedef void __attribute__((address_space(3))) * lptr_t;
 typedef __bf16 __attribute__((ext_vector_type(2))) bf16pair;
 typedef float __attribute__((ext_vector_type(2))) f32x2;
 
+// The 16-bit operand type of every kernel that includes this header is ONE
+// compile-time choice: bf16 (libveon_hip.so, the default) or IEEE fp16
+// (libveon_hip_f16.so, the same sources compiled with -DVEON_HALF_FP16: BASELINE
+// configs[4] asks for fp16).  Kernels keep the historical names (bf16_t, f2bf,
+// bf2f, pack_bf16): they mean "the half type of this build".  Both MFMA
+// instructions share the 16x16x32 fragment layout above; accumulation is fp32.
+#include "half_mode.h"
+#ifdef VEON_HALF_FP16
+typedef _Float16 __attribute__((ext_vector_type(2))) halfpair;
+typedef _Float16 __attribute__((ext_vector_type(8))) half8_native;
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  // v_cvt_f16_f32: round to nearest even, overflow to +-inf
+  return __builtin_bit_cast(bf16_t, (_Float16)f);
+}
+__device__ __forceinline__ float bf2f(bf16_t h) {
+  return (float)__builtin_bit_cast(_Float16, h);
+}
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, halfpair));
+}
+__device__ __forceinline__ f32x4 mfma_16x16x32(bf16x8 a, bf16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_native, a),
+                                                __builtin_bit_cast(half8_native, b), c, 0, 0,
+                                                0);
+}
+#else
 __device__ __forceinline__ bf16_t f2bf(float f) {
   // plain cast: hipcc emits v_cvt_pk_bf16_f32 (round to nearest even, NaN kept)
   return __builtin_bit_cast(bf16_t, (__bf16)f);
@@ -31,6 +57,10 @@ __device__ __forceinline__ float bf2f(bf16_t h) {
 __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
   return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, bf16pair));
 }
+__device__ __forceinline__ f32x4 mfma_16x16x32(bf16x8 a, bf16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+#endif
 
 // erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below the bf16
 // rounding of the output): one rcp, one exp, five FMAs instead of libm's erff.

@@ -344,8 +344,8 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_bf16(
         for (int j = 0; j < 4; ++j)
           // weight rows as MFMA "A", token rows as "B":
           // acc[i][j][reg] = C[token i*16 + fr][feature j*16 + 4*fg + reg]
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i],
-                                                               acc[i][j], 0, 0, 0);
+          acc[i][j] = mfma_16x16x32(fw[j], fa[i],
+                                                               acc[i][j]);
     }
     __syncthreads();  // next slab landed (vmcnt drained) and this one released
   }
@@ -503,8 +503,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_ring(
       for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i], acc[i][j],
-                                                               0, 0, 0);
+          acc[i][j] = mfma_16x16x32(fw[j], fa[i], acc[i][j]);
           if (ILV) {
             const int c = ks * MT * NT + i * NT + j;  // compile-time after unrolling
             if (c % MPP == MPP - 1 && c / MPP < P) {
@@ -664,8 +663,8 @@ __global__ __launch_bounds__(256, 2) void k_attention(
 #pragma unroll
       for (int i = 0; i < QT; ++i) {
         f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
-        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf0, qf[i][0], a, 0, 0, 0);
-        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf1, qf[i][1], a, 0, 0, 0);
+        a = mfma_16x16x32(kf0, qf[i][0], a);
+        a = mfma_16x16x32(kf1, qf[i][1], a);
         s[i][kt] = a;
       }
     }
@@ -748,7 +747,7 @@ __global__ __launch_bounds__(256, 2) void k_attention(
         vf[4] = v1[0]; vf[5] = v1[1]; vf[6] = v1[2]; vf[7] = v1[3];
 #pragma unroll
         for (int i = 0; i < QT; ++i)
-          o[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[i], o[i][j], 0, 0, 0);
+          o[i][j] = mfma_16x16x32(vf, pf[i], o[i][j]);
       }
     }
   };

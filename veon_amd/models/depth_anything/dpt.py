@@ -16,11 +16,12 @@ from ... import conv3d_ops, vit_ops
 from ..builder import register_neck
 from .._native_cache import NativeCacheMixin
 from .dinov2 import DINOv2Adaptor
+from ... import half as _half
 
 
 def _hip_convs_ok(x, *convs):
     """bf16 inference on a ROCm device with MFMA-shaped channel counts."""
-    return (x.is_cuda and x.dtype == torch.bfloat16 and not torch.is_grad_enabled()
+    return (x.is_cuda and x.dtype == _half.dtype() and not torch.is_grad_enabled()
             and all(c.in_channels % 64 == 0 and c.kernel_size == (3, 3)
                     and c.stride == (1, 1) and c.padding == (1, 1) for c in convs))
 
@@ -126,7 +127,7 @@ class FeatureFusionBlock(NativeCacheMixin, nn.Module):
             oc = self.out_conv
             self.__dict__['_hip_1x1'] = (
                 oc.weight.detach().float().view(oc.out_channels, -1)
-                .to(torch.bfloat16).contiguous(),
+                .to(_half.dtype()).contiguous(),
                 oc.bias.detach().float().contiguous())
         w, bias = self.__dict__['_hip_1x1']
         z = self._buf('1x1', B, w.shape[0], H, W, x0.device)
@@ -202,7 +203,7 @@ class DPTHead(NativeCacheMixin, nn.Module):
         oc2 = s.output_conv2
         if (all(getattr(s, 'refinenet%d' % i).hip_ok(l1) for i in (1, 2, 3, 4))
                 and _hip_convs_ok(l1, s.output_conv1, oc2[0])
-                and all(t.dtype == torch.bfloat16 for t in (l2, l3, l4))):
+                and all(t.dtype == _half.dtype() for t in (l2, l3, l4))):
             return self._hip_refine(l1, l2, l3, l4, patch_h, patch_w)
         p4 = s.refinenet4(l4, size=l3.shape[2:])
         p3 = s.refinenet3(p4, l3, size=l2.shape[2:])
@@ -221,7 +222,7 @@ class DPTHead(NativeCacheMixin, nn.Module):
         MFMA conv kernel; see ``_hip_front``."""
         s = self.scratch
         rl = self.resize_layers
-        return (not self.use_clstoken and rows.is_cuda and rows.dtype == torch.bfloat16
+        return (not self.use_clstoken and rows.is_cuda and rows.dtype == _half.dtype()
                 and not torch.is_grad_enabled() and rows.shape[-1] % 64 == 0
                 and isinstance(rl[0], nn.ConvTranspose2d) and rl[0].kernel_size == (4, 4)
                 and isinstance(rl[1], nn.ConvTranspose2d) and rl[1].kernel_size == (2, 2)
@@ -244,7 +245,7 @@ class DPTHead(NativeCacheMixin, nn.Module):
             b1 = torch.zeros(ocp, device=dev)
             w1[:oc] = pj.weight.detach().float().view(oc, d)
             b1[:oc] = pj.bias.detach().float()
-            lv = {'ocp': ocp, 'w1': w1.to(torch.bfloat16).contiguous(), 'b1': b1}
+            lv = {'ocp': ocp, 'w1': w1.to(_half.dtype()).contiguous(), 'b1': b1}
             rl = self.resize_layers[i]
             if isinstance(rl, nn.ConvTranspose2d):
                 # out[(s*y+i, s*x+j), co] = b[co] + sum_c in[(y,x), c] W[c, co, i, j]
@@ -253,7 +254,7 @@ class DPTHead(NativeCacheMixin, nn.Module):
                 w2[:, :, :oc, :oc] = rl.weight.detach().float().permute(2, 3, 1, 0)
                 b2 = torch.zeros(k, k, ocp, device=dev)
                 b2[:, :, :oc] = rl.bias.detach().float()
-                lv.update(s=k, w2=w2.view(k * k * ocp, ocp).to(torch.bfloat16).contiguous(),
+                lv.update(s=k, w2=w2.view(k * k * ocp, ocp).to(_half.dtype()).contiguous(),
                           b2=b2.view(-1).contiguous())
             elif isinstance(rl, nn.Conv2d):
                 wc = torch.zeros(ocp, ocp, 3, 3, device=dev)
@@ -351,7 +352,7 @@ class DPTHead(NativeCacheMixin, nn.Module):
             act = 'none' if len(tail) == 1 else \
                 ('sigmoid' if isinstance(tail[1], nn.Sigmoid) else 'relu')
             return conv3d_ops.image_dot(o, w, b, act)
-        out = conv3d_ops.unpack_image(o, torch.bfloat16, channels=oc2[0].out_channels)
+        out = conv3d_ops.unpack_image(o, _half.dtype(), channels=oc2[0].out_channels)
         for layer in tail:
             out = layer(out)
         return out
@@ -400,7 +401,7 @@ class DepthAnythingV2Adaptor(nn.Module):
 
     def forward(self, x):
         patch_h, patch_w = x.shape[-2] // 14, x.shape[-1] // 14
-        if (self.head_dtype == torch.bfloat16 and x.is_cuda
+        if (self.head_dtype == _half.dtype() and x.is_cuda
                 and not torch.is_grad_enabled() and not self.training):
             # native: the encoder hands over LayerNormed bf16 token rows of the four
             # taps, the head consumes them without a PyTorch op in between

@@ -21,6 +21,7 @@ import torch.nn as nn
 
 from ... import conv3d_ops, vit_ops
 from .._native_cache import NativeCacheMixin
+from ... import half as _half
 
 
 class ConvModule3d(NativeCacheMixin, nn.Module):
@@ -73,7 +74,7 @@ def _pointwise(vol, cm, out_channels=None, epilogue=None):
         sc = torch.ones(npad, device=w.device)
         sh = torch.zeros(npad, device=w.device)
         sc[:cout], sh[:cout] = scale, shift
-        cm.__dict__['_hip'] = (w.to(torch.bfloat16).contiguous(), sc, sh, npad)
+        cm.__dict__['_hip'] = (w.to(_half.dtype()).contiguous(), sc, sh, npad)
     w, sc, sh, npad = cm.__dict__['_hip']
     B, C, Z, Y, X = vol.shape
     key = (B, npad, Z, Y, X, str(vol.device))
@@ -209,9 +210,9 @@ def classifier_logits_low(ov_classifier_weight, feat_occ):
         wp[:Q, :C] = W.detach().float()
         if Cv % 64 == 0:
             logits = torch.zeros(vol.M, qp, dtype=torch.float32, device=W.device)
-            vit_ops.linear_residual_(logits, vol.rows, wp.to(torch.bfloat16).contiguous())
+            vit_ops.linear_residual_(logits, vol.rows, wp.to(_half.dtype()).contiguous())
         else:   # a K the MFMA tile does not divide (toy widths): rocBLAS, same operands
-            logits = vol.rows.float() @ wp.to(torch.bfloat16).float().t()
+            logits = vol.rows.float() @ wp.to(_half.dtype()).float().t()
         return logits.view(B, Z + 2, Y + 2, X + 2, qp)[:, 1:-1, 1:-1, 1:-1, :Q] \
             .permute(0, 4, 1, 2, 3)
     return torch.einsum('qc,bczhw->bqzhw', W, feat_occ)

@@ -13,6 +13,7 @@ import torch.nn.functional as F
 
 from ... import vit_ops
 from .._native_cache import NativeCacheMixin
+from ... import half as _half
 
 
 class LayerNorm(nn.Module):
@@ -73,7 +74,7 @@ class CatFusionLift(NativeCacheMixin, nn.Module):
     def _hip_ok(self, x1, x2):
         c1 = self.input_proj_1[1]
         c2 = self.input_proj_2[1]
-        return (self.hip_dtype == torch.bfloat16 and x1.is_cuda and not self.training
+        return (self.hip_dtype == _half.dtype() and x1.is_cuda and not self.training
                 and not torch.is_grad_enabled() and c1.in_channels % 64 == 0
                 and c2.in_channels % 64 == 0 and c1.out_channels % 4 == 0
                 and c2.out_channels % 4 == 0 and c1.in_channels <= 2048)

@@ -24,6 +24,7 @@ import torch.nn.functional as F
 
 from ... import conv3d_ops, vit_ops
 from .._native_cache import NativeCacheMixin
+from ... import half as _half
 
 
 def _interp(x, **kw):
@@ -58,7 +59,7 @@ class FeedForward(NativeCacheMixin, nn.Module):
 
     def _hip_ok(self, x):
         _, fc1, _, fc2 = self.net
-        return (self.conv_dtype == torch.bfloat16 and x.is_cuda and not self.training
+        return (self.conv_dtype == _half.dtype() and x.is_cuda and not self.training
                 and not torch.is_grad_enabled() and fc1.in_features % 64 == 0
                 and fc1.out_features % 64 == 0 and fc2.out_features % 4 == 0
                 and x.dtype == torch.float32)
@@ -123,7 +124,7 @@ class ConvBlock(NativeCacheMixin, nn.Module):
         self.conv_dtype = None
 
     def _hip_ok(self, x):
-        return (self.conv_dtype == torch.bfloat16 and x.is_cuda
+        return (self.conv_dtype == _half.dtype() and x.is_cuda
                 and not torch.is_grad_enabled() and not self.training
                 and self.dim % 64 == 0 and self.h_dim % 64 == 0
                 and self.h_dim % 8 == 0 and self.out_dim % 8 == 0)
@@ -210,7 +211,7 @@ class HighresSideAdaptorBlock(nn.Module):
 
     def forward(self, x, x_pos, ext, ext_pos, offset=None, offset_shape=(1, 1)):
         B, C_clip, h_ext, w_ext = ext.shape
-        native = self.ff.conv_dtype == torch.bfloat16 and not self.training
+        native = self.ff.conv_dtype == _half.dtype() and not self.training
         x = _ln(self.pre_norm, x, native)
         x = self.ff(x, offset_shape, residual=x, pre_ln=self.ln_3)
         if offset is not None:
@@ -244,7 +245,7 @@ class AttnManipulateBlock(nn.Module):
         self.ln_4 = nn.LayerNorm(mlp_dim)
 
     def forward(self, x, side_shape=(1, 1), new_shape=(1, 1)):
-        native = self.ff.conv_dtype == torch.bfloat16 and not self.training
+        native = self.ff.conv_dtype == _half.dtype() and not self.training
         x = _ln(self.pre_norm, x, native)
         x = _ln(self.ln_4, self.ff(x, side_shape, pre_ln=self.ln_3), native)
         supp = self.head_supp(x)

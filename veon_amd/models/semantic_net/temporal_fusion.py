@@ -31,6 +31,7 @@ import torch.nn.functional as F
 from ... import conv3d_ops, vit_ops
 from .._native_cache import NativeCacheMixin
 from .align_net_body import ConvModule3d
+from ... import half as _half
 
 
 def _conv_bn(cin, cout):
@@ -159,7 +160,7 @@ class TemporalDeformable(NativeCacheMixin, nn.Module):
         p = self.__dict__.get('_hip')
         if p is None:
             C = self.channels
-            bf = lambda w: w.detach().reshape(w.shape[0], -1).to(torch.bfloat16).contiguous()
+            bf = lambda w: w.detach().reshape(w.shape[0], -1).to(_half.dtype()).contiguous()
             c1, c2 = self.offset_conv[0], self.offset_conv[2]
             bn = self.final_norm
             g = bn.weight.detach().float() / torch.sqrt(bn.running_var.float() + bn.eps)

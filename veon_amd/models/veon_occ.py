@@ -37,6 +37,7 @@ from .builder import build_neck
 from .semantic_net import (AlignNetOcc3D, ClipRecHead, ClipVisualTrunk,
                            classifier_logits_low, semantic_inference_3d_fused)
 from .semantic_net.hsa_network import HighresSideAdaptorNetwork
+from .. import half as _half
 
 
 class VeonOccupancyPath(nn.Module):
@@ -105,10 +106,10 @@ class VeonOccupancyPath(nn.Module):
         self.input_size, self.num_cam, self.occ_size = input_size, num_cam, occ_size
         self.two_streams = two_streams
         if bf16_heads:
-            self.depth_model.head_dtype = torch.bfloat16
-            self.hsa.set_conv_dtype(torch.bfloat16)
+            self.depth_model.head_dtype = _half.dtype()
+            self.hsa.set_conv_dtype(_half.dtype())
             for layer in self.occ_decoder.fusion_layers.values():
-                layer.hip_dtype = torch.bfloat16
+                layer.hip_dtype = _half.dtype()
         self.__dict__['_side'] = None
 
     # ------------------------------------------------------------- branches

@@ -9,6 +9,7 @@ import ctypes
 import torch
 
 from . import _lib
+from . import half as _half
 
 EPI_BF16, EPI_GELU, EPI_QUICKGELU, EPI_RESID = 0, 1, 2, 3
 EPI_AFFINE, EPI_AFFINE_RELU = 4, 5
@@ -23,7 +24,7 @@ def to_bf16(x):
     """fp32 -> bf16 (round to nearest even) on the device."""
     dev = _dev(x)
     x = x.contiguous().float()
-    out = torch.empty(x.shape, dtype=torch.bfloat16, device=dev)
+    out = torch.empty(x.shape, dtype=_half.dtype(), device=dev)
     with torch.cuda.device(dev):
         st = _lib.lib().veon_vit_cast_bf16(_lib.ptr(x), _lib.ptr(out), x.numel(),
                                            _lib.stream_ptr(dev))
@@ -39,7 +40,7 @@ def patchify(img, patch, skip=0, kpad=None):
     B, C, H, W = img.shape
     k = C * patch * patch
     kpad = kpad or (k + 63) // 64 * 64
-    out = torch.empty((B * (skip + (H // patch) * (W // patch)), kpad), dtype=torch.bfloat16,
+    out = torch.empty((B * (skip + (H // patch) * (W // patch)), kpad), dtype=_half.dtype(),
                       device=dev)
     with _lib.on_device(dev):
         st = _lib.lib().veon_vit_patchify(_lib.ptr(img), _lib.ptr(out), B, C, H, W, patch,
@@ -55,7 +56,7 @@ def layernorm(x, weight, bias, eps=1e-6, out=None):
     T = x.numel() // d
     assert x.dtype == torch.float32 and x.is_contiguous()
     if out is None:
-        out = torch.empty(x.shape, dtype=torch.bfloat16, device=dev)
+        out = torch.empty(x.shape, dtype=_half.dtype(), device=dev)
     with torch.cuda.device(dev):
         st = _lib.lib().veon_vit_layernorm(
             _lib.ptr(x), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(out), T, d,
@@ -83,14 +84,14 @@ def linear(a, w, bias=None, epilogue=EPI_BF16, out=None, gamma=None):
     """a bf16 [M,K], w bf16 [N,K] (nn.Linear layout) -> bf16 [M,N].  ``gamma``
     (fp32 [N]) is the per-feature scale of the EPI_AFFINE* epilogues."""
     dev = _dev(a, w)
-    assert a.dtype == torch.bfloat16 and w.dtype == torch.bfloat16
+    assert a.dtype == _half.dtype() and w.dtype == _half.dtype()
     assert a.is_contiguous() and w.is_contiguous()
     K = a.shape[-1]
     M = a.numel() // K
     N = w.shape[0]
     assert w.shape[1] == K
     if out is None:
-        out = torch.empty(a.shape[:-1] + (N,), dtype=torch.bfloat16, device=dev)
+        out = torch.empty(a.shape[:-1] + (N,), dtype=_half.dtype(), device=dev)
     with torch.cuda.device(dev):
         st = _lib.lib().veon_vit_gemm(
             _lib.ptr(a), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(gamma),
@@ -124,9 +125,9 @@ def attention(qkv, num_heads, bias=None, out=None):
     B, T, three_d = qkv.shape
     H = num_heads
     hd = three_d // (3 * H)
-    assert qkv.dtype == torch.bfloat16 and qkv.is_contiguous()
+    assert qkv.dtype == _half.dtype() and qkv.is_contiguous()
     if out is None:
-        out = torch.empty((B, T, H * hd), dtype=torch.bfloat16, device=dev)
+        out = torch.empty((B, T, H * hd), dtype=_half.dtype(), device=dev)
     sb = sh = 0
     if bias is not None:
         assert bias.dtype == torch.float32 and bias.dim() == 4
