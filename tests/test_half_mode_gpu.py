@@ -129,9 +129,9 @@ def test_native_path_logits_match_reference_chain_fp16():
     """BASELINE.json: "voxel logits matching the reference within a stated fp16
     tolerance".  Native path with fp16 operands on MFMA (fp32 accumulation, HIP lift
     with the fused max-pool) against the fp32 logits of the chain of the reference's
-    own modules (tests/golden/path_tiny.npz): relative L2 <= 1e-2, max |diff| <= 2e-2
-    of the logit range, arg-max agreement >= 99 % (bf16 flavour: 4e-2 / 8e-2 / 97 %,
-    tests/test_path_golden.py)."""
+    own modules (tests/golden/path_tiny.npz): relative L2 <= 2e-3, max |diff| <= 2e-3
+    of the logit range, arg-max agreement >= 99.5 % (measured 6.2e-4 / 4.9e-4; the bf16
+    flavour is held to 4e-2 / 8e-2 / 97 % in tests/test_path_golden.py)."""
     from tests.test_path_golden import _build, _inputs
     g = load_golden('path_tiny')
     net = _build(g, DEV, native=True)
@@ -144,10 +144,10 @@ def test_native_path_logits_match_reference_chain_fp16():
         rel = ((got - ref).norm() / ref.norm()).item()
         mx = ((got - ref).abs().max() / (ref.max() - ref.min())).item()
         print('fp16 path %s: rel L2 %.3e, max/range %.3e' % (k, rel, mx))
-        assert rel <= 1e-2 and mx <= 2e-2, (k, rel, mx)
+        assert rel <= 2e-3 and mx <= 2e-3, (k, rel, mx)
     ref_cls = torch.from_numpy(g['sem_occ']).to(DEV).argmax(1)
     agree = (out['sem_occ'].argmax(1) == ref_cls).float().mean().item()
-    assert agree >= 0.99, agree
+    assert agree >= 0.995, agree
 
 
 def test_veon_l_preset_fp16_graph_replay():

@@ -32,7 +32,7 @@ import torch
 import torch.nn.functional as F
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from veon_amd import conv3d_ops, synthetic  # noqa: E402
+from veon_amd import conv3d_ops, half, synthetic  # noqa: E402
 from veon_amd.graphs import GraphedCallable  # noqa: E402
 from veon_amd.models import build_neck  # noqa: E402
 from veon_amd.models.semantic_net import (AlignBody3D, ClipVisualTrunk,  # noqa: E402
@@ -77,7 +77,7 @@ def run(enc='vitb', head_bf16=True, graph_clip=False, dev='cuda:0', iters=20,
     dav2 = build_neck(dict(type='DepthAnythingV2Adaptor', max_depth=80.0,
                            use_lora=True, lora_r=16, **cfgs[enc])).to(dev).eval()
     if head_bf16:
-        dav2.head_dtype = torch.bfloat16
+        dav2.head_dtype = half.dtype()
     clip = ClipVisualTrunk(224, 16, 768, 12, 12).to(dev).eval()
     proj = torch.nn.Conv2d(768, 256, 1).to(dev).eval()
     vt = build_neck(dict(type='LSSViewTransformerRaw', grid_config=synthetic.GRID_VEON,
