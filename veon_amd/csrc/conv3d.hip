@@ -109,7 +109,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv3d_k3(
 #pragma unroll
   for (int j = 0; j < WP; ++j) {
     const int r = (wave + j * NW) * 8 + (lane >> 3);
-    const int c = (lane & 7) ^ (r & 7);
+    const int c = (lane & 7) ^ swz_w(r);
     const int gn = n0 + r < Cout ? n0 + r : Cout - 1;
     srcW[j] = W + (int64_t)gn * K + c * 8;
   }
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv3d_k3(
     // rows 4 fg .. 4 fg + 3 of tiles 2p and 2p + 1 are the 8 consecutive features
     // 32 p + 8 fg + 0..7 (16-byte epilogue accesses instead of 8-byte ones)
     const int rw = wn * 64 + (i / 2) * 32 + (fr / 4) * 8 + (i & 1) * 4 + (fr & 3);
-    offW[i] = rw * CBK + ((fg ^ (rw & 7)) * 8);
+    offW[i] = rw * CBK + ((fg ^ swz_w(rw)) * 8);
   }
 
   const int nk = ntaps * cpk;
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv3d_k3_ax(
 #pragma unroll
   for (int j = 0; j < WP; ++j) {
     const int r = (wave + j * NW) * 8 + (lane >> 3);
-    const int c = (lane & 7) ^ (r & 7);
+    const int c = (lane & 7) ^ swz_w(r);
     const int gn = n0 + r < Cout ? n0 + r : Cout - 1;
     srcW[j] = gn * K + c * 8;
   }
@@ -357,7 +357,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv3d_k3_ax(
     // rows 4 fg .. 4 fg + 3 of tiles 2p and 2p + 1 are the 8 consecutive features
     // 32 p + 8 fg + 0..7 (16-byte epilogue accesses instead of 8-byte ones)
     const int rw = wn * 64 + (i / 2) * 32 + (fr / 4) * 8 + (i & 1) * 4 + (fr & 3);
-    offW[i] = rw * CBK + ((fg ^ (rw & 7)) * 8);
+    offW[i] = rw * CBK + ((fg ^ swz_w(rw)) * 8);
   }
 
   auto compute = [&](int g, int st, int dx) {

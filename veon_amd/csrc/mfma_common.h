@@ -62,6 +62,23 @@ __device__ __forceinline__ f32x4 mfma_16x16x32(bf16x8 a, bf16x8 b, f32x4 c) {
 }
 #endif
 
+// XOR key of the 16-byte-chunk permutation inside a 128-byte LDS row (the
+// "swizzle"): physical chunk = logical chunk ^ key(row), applied on the DMA source
+// address and again on the fragment read.  ds_read_b128 is served in four
+// NON-contiguous 16-lane groups ({0-3,12-15,20-27}, ...) over 16 slots of 16 bytes,
+// slot = (row & 1) * 8 + physical chunk for 128-byte rows.
+//  * token / activation rows: a fragment's 16 lanes read 16 CONSECUTIVE rows from
+//    any base -> key = row & 7 is conflict-free.
+//  * weight rows: the paired tiles read rows {0-3, 8-11, 16-19, 24-27} (+4) of
+//    their 32-row block (weight_row: 16-byte epilogues), where row & 7 only takes
+//    four values -> every weight fragment read was 2-way conflicted (8 LDS cycles
+//    instead of 4; PMC SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 16/36 = 44.4 % for
+//    the 64x128 GEMM tile, 16/60 = 26.7 % for the conv: profiles/r02_lds_pmc.txt).
+//    swz_w takes bit 3 of the row in place of bit 2: conflict-free for those rows
+//    and for the 16 consecutive rows of an unpaired tile.
+__device__ __forceinline__ int swz_a(int row) { return row & 7; }
+__device__ __forceinline__ int swz_w(int row) { return (row & 3) | ((row >> 1) & 4); }
+
 // erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below the bf16
 // rounding of the output): one rcp, one exp, five FMAs instead of libm's erff.
 __device__ __forceinline__ float erf_as(float x) {

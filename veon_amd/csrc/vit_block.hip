@@ -283,7 +283,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_bf16(
 #pragma unroll
   for (int j = 0; j < WP; ++j) {
     const int r = (wave + j * NW) * 8 + (lane >> 3);
-    const int c = (lane & 7) ^ (r & 7);
+    const int c = (lane & 7) ^ swz_w(r);
     const int gn = n0 + r < N ? n0 + r : N - 1;
     srcW[j] = W + (int64_t)gn * K + c * 8;
   }
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_bf16(
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int rw = wn * 64 + weight_row<4>(i, fr);
-    offW[i] = rw * BK + ((fg ^ (rw & 7)) * 8);
+    offW[i] = rw * BK + ((fg ^ swz_w(rw)) * 8);
   }
 
   const int nk = K / BK;
@@ -419,7 +419,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_ring(
 #pragma unroll
   for (int j = 0; j < P; ++j) {
     const int r = (wave + j * NW) * 8 + (lane >> 3);
-    const int c = (lane & 7) ^ (r & 7);
+    const int c = (lane & 7) ^ (r < BM ? swz_a(r) : swz_w(r - BM));
     if (r < BM) {
       const int gm = m0 + r < M ? m0 + r : M - 1;
       src[j] = A + (int64_t)gm * K + c * 8;
@@ -450,7 +450,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_ring(
 #pragma unroll
   for (int i = 0; i < NT; ++i) {
     const int rw = wn * (16 * NT) + weight_row<NT>(i, fr);
-    offW[i] = A_ELEMS + rw * BK + ((fg ^ (rw & 7)) * 8);
+    offW[i] = A_ELEMS + rw * BK + ((fg ^ swz_w(rw)) * 8);
   }
 
   const int nk = K / BK;
