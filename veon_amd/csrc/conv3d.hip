@@ -301,21 +301,29 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv3d_k3_ax(
   // DMA map as k_gemm_bf16: a wave instruction fills 8 rows of a slab; lane l
   // lands in row r = 8*piece + l/8, physical chunk l%8, and fetches logical
   // chunk (l%8) ^ (r&7).  Activation rows are NOT clamped (guard rows).
-  // 32-bit element offsets (the launcher checks the extents): 64-bit pointers per
-  // piece cost the 168-VGPR budget of the 12-wave tile a spill
+  // The DMA is buffer_load ... lds (MUBUF), not global_load_lds: the latter is a
+  // FLAT-encoded instruction that may touch LDS, after which hipcc's waitcnt pass
+  // turns every counted s_waitcnt lgkmcnt(N) of the fragment pipeline below into
+  // lgkmcnt(0) ("pending flat").  Per-lane 32-bit BYTE offsets in VGPRs, the slab's
+  // tap offset in an SGPR (the launcher checks the extents: < 2^31 elements).  The
+  // activation descriptor starts ((Yp + 1) Xp + 1) rows before `in` (inside the
+  // guard rows), so that the most negative tap offset is still a positive offset.
+  const int abias = ((Yp + 1) * Xp + 1) * Cin;
+  const rsrc_t rsA = make_rsrc(in - abias);
+  const rsrc_t rsW = make_rsrc(W);
   int srcA[AP], srcW[WP];
 #pragma unroll
   for (int j = 0; j < AP; ++j) {
     const int r = (wave + j * NW) * 8 + (lane >> 3);
     const int c = (lane & 7) ^ (r & 7);
-    srcA[j] = (m0 - 1 + r) * Cin + c * 8;
+    srcA[j] = 2 * ((m0 - 1 + r) * Cin + c * 8);
   }
 #pragma unroll
   for (int j = 0; j < WP; ++j) {
     const int r = (wave + j * NW) * 8 + (lane >> 3);
     const int c = (lane & 7) ^ swz_w(r);
     const int gn = n0 + r < Cout ? n0 + r : Cout - 1;
-    srcW[j] = gn * K + c * 8;
+    srcW[j] = 2 * (gn * K + c * 8);
   }
   const int cpk = Cin / CBK;  // channel chunks
   // group g = (dz, dy, channel chunk): one activation slab, three weight slabs
@@ -324,23 +332,21 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv3d_k3_ax(
     bf16_t* dA = smem + (g & 1) * A_ELEMS;
     const int zy = g / cpk, cc = (g - zy * cpk) * CBK;
     const int dz = kd == 3 ? zy / 3 - 1 : 0, dy = zy % 3 - 1;
-    const int ao = ((dz * Yp + dy) * Xp) * Cin + cc;
+    const int ao = 2 * (((dz * Yp + dy) * Xp) * Cin + cc + abias);
 #pragma unroll
     for (int j = 0; j < AP; ++j)
       if (wave + j * NW < APIECES)  // wave-uniform
-        __builtin_amdgcn_global_load_lds((gptr_t)(in + (srcA[j] + ao)),
-                                         (lptr_t)(dA + (wave + j * NW) * 512), 16, 0, 0);
+        buffer_load_lds16(rsA, (lptr_t)(dA + (wave + j * NW) * 512), srcA[j], ao);
   };
   auto dma_w = [&](int st) {   // st = 3 g + dx
     bf16_t* dW = smem + 2 * A_ELEMS + (st & 1) * CW_ELEMS;
     const int g = st / 3, dx = st - g * 3;
     const int zy = g / cpk, cc = (g - zy * cpk) * CBK;
-    const int wk = (zy * 3 + dx) * Cin + cc;
+    const int wk = 2 * ((zy * 3 + dx) * Cin + cc);
 #pragma unroll
     for (int j = 0; j < WP; ++j)
       if (wave + j * NW < WPIECES)
-        __builtin_amdgcn_global_load_lds((gptr_t)(W + (srcW[j] + wk)),
-                                         (lptr_t)(dW + (wave + j * NW) * 512), 16, 0, 0);
+        buffer_load_lds16(rsW, (lptr_t)(dW + (wave + j * NW) * 512), srcW[j], wk);
   };
 
   f32x4 acc[MT][4];
@@ -360,31 +366,46 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv3d_k3_ax(
     offW[i] = rw * CBK + ((fg ^ swz_w(rw)) * 8);
   }
 
+  // One k-step = 2 * MT activation fragments against 2 x 4 weight fragments.  The
+  // activation fragments run through a ring of kPD + 1 registers: the read of
+  // fragment q + kPD is issued BEFORE the four MFMAs of fragment q, so its LDS
+  // latency passes under 4 * kPD MFMAs (the compiler's own order was "read two,
+  // s_waitcnt lgkmcnt(0), eight MFMAs": every read fully exposed).  The weight
+  // fragments of the second half are re-read one by one as the last MFMAs of the
+  // first half release them.  sched_barrier pins the order; the waits the compiler
+  // inserts are counted (LDS returns in order).
+  constexpr int kPD = 2;
+  constexpr int NQ = (CBK / 32) * MT;
   auto compute = [&](int g, int st, int dx) {
     const bf16_t* tA = smem + (g & 1) * A_ELEMS;
     const bf16_t* tW = smem + 2 * A_ELEMS + (st & 1) * CW_ELEMS;
-    int offA[MT];
+    const int ra = ra0 + dx;   // + 16 i: the low three bits of the row do not change
+    const bf16_t* pA = tA + (ra * CBK + ((fg ^ (ra & 7)) * 8));
+    auto lda = [&](int q) {   // q = ks * MT + i, compile-time after unrolling
+      const int ks = q / MT, i = q - ks * MT;
+      // (x + i * 16 * CBK) ^ 32 == (x ^ 32) + i * 16 * CBK: bit 5 is not touched
+      return *reinterpret_cast<const bf16x8*>(
+          tA + (((int)(pA - tA) ^ (ks * 32)) + i * 16 * CBK));
+    };
+    bf16x8 fw[4], fa[kPD + 1];
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      const int ra = ra0 + i * 16 + dx;
-      offA[i] = ra * CBK + ((fg ^ (ra & 7)) * 8);
-    }
+    for (int j = 0; j < 4; ++j)
+      fw[j] = *reinterpret_cast<const bf16x8*>(tW + offW[j]);
 #pragma unroll
-    for (int ks = 0; ks < CBK / 32; ++ks) {
-      bf16x8 fa[MT], fw[4];
+    for (int q = 0; q < kPD; ++q) fa[q] = lda(q);
 #pragma unroll
-      for (int i = 0; i < MT; ++i)
-        fa[i] = *reinterpret_cast<const bf16x8*>(tA + (offA[i] ^ (ks * 32)));
+    for (int q = 0; q < NQ; ++q) {
+      if (q + kPD < NQ) fa[(q + kPD) % (kPD + 1)] = lda(q + kPD);
+      __builtin_amdgcn_sched_barrier(0);
+      const int i = q % MT;
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        fw[j] = *reinterpret_cast<const bf16x8*>(tW + (offW[j] ^ (ks * 32)));
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          // acc[i][j][reg] = C[voxel i*16 + fr][feature j*16 + 4*fg + reg]
-          acc[i][j] = mfma_16x16x32(fw[j], fa[i],
-                                                               acc[i][j]);
+      for (int j = 0; j < 4; ++j) {
+        // acc[i][j][reg] = C[voxel i*16 + fr][feature j*16 + 4*fg + reg]
+        acc[i][j] = mfma_16x16x32(fw[j], fa[q % (kPD + 1)], acc[i][j]);
+        if (q == MT - 1 && CBK / 32 > 1)   // fw[j] is free: fetch its second half
+          fw[j] = *reinterpret_cast<const bf16x8*>(tW + (offW[j] ^ 32));
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
   };
   dma_a(0);

@@ -79,6 +79,28 @@ __device__ __forceinline__ f32x4 mfma_16x16x32(bf16x8 a, bf16x8 b, f32x4 c) {
 __device__ __forceinline__ int swz_a(int row) { return row & 7; }
 __device__ __forceinline__ int swz_w(int row) { return (row & 3) | ((row >> 1) & 4); }
 
+// LDS DMA through the buffer path (buffer_load_dwordx4 ... lds, MUBUF): base from a
+// raw buffer descriptor, per-lane byte offset in a VGPR, a uniform byte offset in an
+// SGPR; lane l lands at dst + 16 l.  Unlike global_load_lds (FLAT encoding) it does
+// not make hipcc's waitcnt pass fall back from counted s_waitcnt lgkmcnt(N) to
+// lgkmcnt(0) on the LDS reads around it.  The descriptor type exists only in the
+// device pass; the host pass just parses kernel bodies.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const void* base) {
+  // no bounds (0xffffffff records), DATA_FORMAT = 32-bit (gfx9 family dword 3)
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0xffffffff, 0x00020000);
+}
+__device__ __forceinline__ void buffer_load_lds16(rsrc_t r, lptr_t dst, int voffset,
+                                                  int soffset) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, dst, 16, voffset, soffset, 0, 0);
+}
+#else
+typedef int rsrc_t;
+__device__ inline rsrc_t make_rsrc(const void*) { return 0; }
+__device__ inline void buffer_load_lds16(rsrc_t, lptr_t, int, int) {}
+#endif
+
 // erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below the bf16
 // rounding of the output): one rcp, one exp, five FMAs instead of libm's erff.
 __device__ __forceinline__ float erf_as(float x) {
