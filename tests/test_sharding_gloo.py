@@ -166,7 +166,7 @@ def _tiny_path(ncam):
     return net, images, geom
 
 
-def _path_worker(rank, world, port, ncam, q):
+def _path_worker(rank, world, port, ncam, q, reduce='allreduce'):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
@@ -174,7 +174,7 @@ def _path_worker(rank, world, port, ncam, q):
         torch.set_num_threads(2)
         net, images, geom = _tiny_path(ncam)
         with torch.no_grad():
-            out = net.forward_camera_sharded(images, geom)
+            out = net.forward_camera_sharded(images, geom, reduce=reduce)
             full = net.from_volume(net.lift_cameras(images, geom, 0, ncam))
         gathered = [torch.empty_like(out['sem_occ']) for _ in range(world)]
         dist.all_gather(gathered, out['sem_occ'])
@@ -188,15 +188,20 @@ def _path_worker(rank, world, port, ncam, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('world,ncam', [(2, 3), (3, 2)])
-def test_camera_sharded_occupancy_path_matches_unsharded(world, ncam):
+@pytest.mark.parametrize('world,ncam,reduce', [(2, 3, 'allreduce'), (3, 2, 'allreduce'),
+                                               (2, 3, 'scatter'), (4, 3, 'scatter'),
+                                               (3, 2, 'scatter')])
+def test_camera_sharded_occupancy_path_matches_unsharded(world, ncam, reduce):
     """Each rank: encoders + HSA + fusion + lift of its cameras -> all-reduce of the
     un-pooled volume -> max-pool -> body / heads / classifier; equals the unsharded
-    path up to the reduce's summation order; ranks without a camera add zeros."""
+    path up to the reduce's summation order; ranks without a camera add zeros.
+    reduce='scatter': reduce-scatter over channel slices, max-pool of the own slice,
+    all-gather of the pooled slices (16 channels: worlds 2 and 4 take it, world 3
+    falls back to the all-reduce)."""
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_path_worker, args=(r, world, port, ncam, q))
+    procs = [ctx.Process(target=_path_worker, args=(r, world, port, ncam, q, reduce))
              for r in range(world)]
     for p in procs:
         p.start()
