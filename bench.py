@@ -71,6 +71,10 @@ def parse():
                    help='replicas: one sample per GPU, no collective (default); '
                         'cameras: the six cameras of ONE sample split over the '
                         'GPUs + RCCL all-reduce of the voxel volume')
+    p.add_argument('--reduce', default='allreduce', choices=['allreduce', 'scatter'],
+                   help='--shard cameras with VEONB / VEONL: one all-reduce of the un-pooled '
+                        'volume, or reduce-scatter over channel slices + sharded max-pool + '
+                        'all-gather of the pooled slices (1.78x fewer link bytes)')
     p.add_argument('--placement', action='store_true',
                    help='also report the kernel into a placement-tuned persistent '
                         'output volume (veon_amd/placement.py) as roofline.placed')
@@ -285,13 +289,16 @@ def bench_hotpath(args, rank, world, dev, dist):
         rd = torch.bfloat16 if os.environ.get('VEON_REDUCE_DTYPE', 'bf16') == 'bf16' else None
 
         def step():
-            return net.forward_camera_sharded(images, geom, reduce_dtype=rd)
+            return net.forward_camera_sharded(images, geom, reduce_dtype=rd,
+                                              reduce=args.reduce)
         with torch.no_grad():
             el = timed_steps(step, args.steps, args.warmup, dist, dev)
         ms = el / args.steps * 1e3
         stages = {k: round(v, 3) for k, v in r.items() if k.endswith('_ms')}
         tf = 8 * 2.0 * 8 * 100 * 100 * 256 * 256 * 27 / (r['body_ms'] * 1e-3) / 1e12
-        launch = 'eager; all-reduce of the un-pooled volume in %s' % (
+        launch = 'eager; %s of the un-pooled volume in %s' % (
+            'all-reduce' if args.reduce == 'allreduce' else
+            'reduce-scatter (channel slices) + sharded max-pool + all-gather',
             'bf16' if rd is not None else 'fp32')
         value, scaling = 1e3 / ms, 'strong'
         par = 'cameras of one sample sharded over %d GPUs + RCCL all-reduce' % world

@@ -20,7 +20,7 @@ timeout -k 10 600 python bench.py > $OUT/bench_default.json 2> $OUT/bench_defaul
 echo "bench exit $?"
 cd /tmp
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_trace -- \
-  python3 $R/bench.py --no-pmc --no-cpu-baseline --no-sv --no-veonb \
+  python3 $R/bench.py --no-pmc --no-cpu-baseline --no-sv --no-veonb --no-veonl \
   > $OUT/bench_profiled.json 2> $OUT/bench_profiled.err
 echo "bench trace exit $?"
 cd $R
