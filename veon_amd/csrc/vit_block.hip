@@ -414,26 +414,37 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_ring(
 
   // DMA map: piece p = wave + j*NW covers LDS rows 8p .. 8p+7 of the stage image
   // (token rows first, then weight rows); lane l lands in row 8p + l/8, physical
-  // chunk l%8, so it fetches logical chunk (l%8) ^ (row & 7).
-  const bf16_t* src[P];
+  // chunk l%8, so it fetches logical chunk (l%8) ^ key(row).  The DMA is
+  // buffer_load ... lds (per-lane BYTE offsets, k0 in an SGPR; the launcher checks
+  // that both matrices stay below 2^31 bytes): after a FLAT-encoded
+  // global_load_lds hipcc's waitcnt pass downgrades every counted lgkmcnt of the
+  // fragment pipeline below to lgkmcnt(0).
+  const rsrc_t rsA = make_rsrc(A), rsW = make_rsrc(W);
+  int src[P];
 #pragma unroll
   for (int j = 0; j < P; ++j) {
     const int r = (wave + j * NW) * 8 + (lane >> 3);
-    const int c = (lane & 7) ^ (r < BM ? swz_a(r) : swz_w(r - BM));
     if (r < BM) {
+      const int c = (lane & 7) ^ swz_a(r);
       const int gm = m0 + r < M ? m0 + r : M - 1;
-      src[j] = A + (int64_t)gm * K + c * 8;
+      src[j] = 2 * (gm * K + c * 8);
     } else {
+      const int c = (lane & 7) ^ swz_w(r - BM);
       const int gn = n0 + (r - BM) < N ? n0 + (r - BM) : N - 1;
-      src[j] = W + (int64_t)gn * K + c * 8;
+      src[j] = 2 * (gn * K + c * 8);
     }
   }
+  auto piece = [&](int j, bf16_t* d, int k0) {
+    // a piece is 8 rows, BM a multiple of 8: token or weight rows, wave-uniform
+    if ((wave + j * NW) * 8 < BM)
+      buffer_load_lds16(rsA, (lptr_t)(d + (wave + j * NW) * 512), src[j], 2 * k0);
+    else
+      buffer_load_lds16(rsW, (lptr_t)(d + (wave + j * NW) * 512), src[j], 2 * k0);
+  };
   auto dma = [&](int stage, int k0) {
     bf16_t* d = smem + stage * STAGE_ELEMS;
 #pragma unroll
-    for (int j = 0; j < P; ++j)
-      __builtin_amdgcn_global_load_lds((gptr_t)(src[j] + k0),
-                                       (lptr_t)(d + (wave + j * NW) * 512), 16, 0, 0);
+    for (int j = 0; j < P; ++j) piece(j, d, k0);
   };
 
   f32x4 acc[MT][NT];
@@ -441,12 +452,11 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_ring(
   for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  int offA[MT], offW[NT];
-#pragma unroll
-  for (int i = 0; i < MT; ++i) {
-    const int ra = wm * (16 * MT) + i * 16 + fr;
-    offA[i] = ra * BK + ((fg ^ (ra & 7)) * 8);
-  }
+  // token fragments: row wm*16*MT + 16 i + fr, whose low three bits do not depend
+  // on i -> one base and compile-time offsets
+  const int ra0 = wm * (16 * MT) + fr;
+  const int baseA = ra0 * BK + ((fg ^ swz_a(ra0)) * 8);
+  int offW[NT];
 #pragma unroll
   for (int i = 0; i < NT; ++i) {
     const int rw = wn * (16 * NT) + weight_row<NT>(i, fr);
@@ -464,9 +474,16 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_ring(
   // cover the issue slot of the DMA.  The refilled stage is needed two barriers
   // later, so its late pieces still have a whole K-step to land.
   constexpr bool ILV = S >= 3;
-  constexpr int MFMAS = 2 * MT * NT;
+  constexpr int KS = BK / 32;
+  constexpr int MFMAS = KS * MT * NT;
   static_assert(MFMAS >= P, "at least one MFMA per DMA piece");
   constexpr int MPP = MFMAS / P;
+  // Fragment pipeline of a K-step: the token fragments run through a ring of
+  // kPD + 1 registers, fragment q + kPD is read BEFORE the NT MFMAs of fragment q
+  // (counted lgkmcnt in steady state); the weight fragments are double-buffered
+  // over the two halves of the K-step (the second half is read while the first
+  // computes).  With 8 waves on the CU (2 per SIMD) nothing else hides that latency.
+  constexpr int kPD = 2, RS = kPD + 1, NQ = KS * MT;
   for (int kt = 0; kt < nk; ++kt) {
     // my pieces of K-step kt have landed when at most S - 2 younger stages are
     // outstanding; at the tail fewer were issued, so drain
@@ -477,45 +494,44 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_ring(
     const int rstage = (kt + S - 1) % S, rk0 = (kt + S - 1) * BK;
     if (!ILV && refill) dma(rstage, rk0);
     const bf16_t* st = smem + (kt % S) * STAGE_ELEMS;
+    bf16_t* rd = smem + rstage * STAGE_ELEMS;
     if (abl & 8) {
       if (ILV && refill) dma(rstage, rk0);
       continue;
     }
-    bf16_t* rd = smem + rstage * STAGE_ELEMS;
+    auto lda = [&](int q) {   // q = ks * MT + i, compile-time after unrolling
+      const int ks = q / MT, i = q - ks * MT;
+      return *reinterpret_cast<const bf16x8*>(st + ((baseA ^ (ks * 32)) + i * 16 * BK));
+    };
+    bf16x8 fw[2][NT], fa[RS];
 #pragma unroll
-    for (int ks = 0; ks < BK / 32; ++ks) {
-      bf16x8 fw[NT], fa[MT];
+    for (int j = 0; j < NT; ++j)
+      fw[0][j] = *reinterpret_cast<const bf16x8*>(st + offW[j]);
 #pragma unroll
-      for (int j = 0; j < NT; ++j)
-        fw[j] = *reinterpret_cast<const bf16x8*>(st + (offW[j] ^ (ks * 32)));
+    for (int q = 0; q < kPD; ++q) fa[q] = lda(q);
 #pragma unroll
-      for (int i = 0; i < MT; ++i)
-        fa[i] = *reinterpret_cast<const bf16x8*>(st + (offA[i] ^ (ks * 32)));
-      if (abl & 4) {  // ablation: fragment reads only
+    for (int q = 0; q < NQ; ++q) {
+      const int ks = q / MT, i = q - ks * MT;
+      if (q + kPD < NQ) fa[(q + kPD) % RS] = lda(q + kPD);
+      if (i == 0 && ks + 1 < KS) {
 #pragma unroll
-        for (int j = 0; j < NT; ++j) asm volatile("" ::"v"(fw[j]));
-#pragma unroll
-        for (int i = 0; i < MT; ++i) asm volatile("" ::"v"(fa[i]));
-        if (ILV && refill && ks == 0) dma(rstage, rk0);
-        continue;
+        for (int j = 0; j < NT; ++j)
+          fw[(ks + 1) & 1][j] =
+              *reinterpret_cast<const bf16x8*>(st + (offW[j] ^ ((ks + 1) * 32)));
       }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-          acc[i][j] = mfma_16x16x32(fw[j], fa[i], acc[i][j]);
-          if (ILV) {
-            const int c = ks * MT * NT + i * NT + j;  // compile-time after unrolling
-            if (c % MPP == MPP - 1 && c / MPP < P) {
-              const int jj = c / MPP;
-              if (refill)
-                __builtin_amdgcn_global_load_lds((gptr_t)(src[jj] + rk0),
-                                                 (lptr_t)(rd + (wave + jj * NW) * 512), 16,
-                                                 0, 0);
-              __builtin_amdgcn_sched_barrier(0);
-            }
+      for (int j = 0; j < NT; ++j) {
+        acc[i][j] = mfma_16x16x32(fw[ks & 1][j], fa[q % RS], acc[i][j]);
+        if (ILV) {
+          const int c = q * NT + j;  // compile-time after unrolling
+          if (c % MPP == MPP - 1 && c / MPP < P) {
+            if (refill) piece(c / MPP, rd, rk0);
+            __builtin_amdgcn_sched_barrier(0);
           }
         }
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
   if (abl & 1) {  // ablation: no epilogue stores
@@ -1032,6 +1048,8 @@ int veon_vit_gemm(const void* a_bf16, const void* w_bf16, const float* bias,
     int sel = g_gemm_ring >= 0 ? g_gemm_ring
                     : epilogue == EPI_RESID ? 0 : gemm_ring_config(M, N, K);
     if (epilogue == EPI_AFFINE_SIGM) sel = 0;   // small-tile kernel only
+    // the ring kernel addresses both matrices with 32-bit byte offsets
+    if ((int64_t)M * K * 2 >= (1ll << 31) || (int64_t)N * K * 2 >= (1ll << 31)) sel = 0;
     if (sel > 0) {
 #define VEON_RING(EPI, WM, WN, MT, NT, S)                                             \
   do {                                                                                \
