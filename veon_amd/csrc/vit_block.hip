@@ -593,8 +593,6 @@ __global__ __launch_bounds__(256, 2) void k_attention(
   const int q0 = (blockIdx.x * 4 + wave) * AQ;
   const int64_t tok_stride = (int64_t)3 * H * HD;
   const bf16_t* qb = qkv + (int64_t)b * T * tok_stride + (int64_t)h * HD;
-  const bf16_t* kb = qb + (int64_t)H * HD;
-  const bf16_t* vb = qb + (int64_t)2 * H * HD;
   constexpr float kLog2e = 1.4426950408889634f;
 
   // DMA map (as the GEMM): wave instruction j (0..1) of wave w fills LDS rows
@@ -607,16 +605,20 @@ __global__ __launch_bounds__(256, 2) void k_attention(
     dr[j] = (wave * 2 + j) * 8 + (lane >> 3);
     dc[j] = ((lane & 7) ^ (dr[j] & 7)) * 8;
   }
+  const rsrc_t rsQ = make_rsrc(qb);   // K rows at +H*HD elements, V rows at +2*H*HD
   auto dma = [&](int buf, int k0) {
     bf16_t* dK = smem + buf * 2 * KV_ELEMS;
     bf16_t* dV = dK + KV_ELEMS;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int key = k0 + dr[j] < T ? k0 + dr[j] : T - 1;
-      const int64_t off = (int64_t)key * tok_stride + dc[j];
+      // byte offset inside this image's qkv rows (the launcher checks < 2^31)
+      const int off = 2 * (key * (int)tok_stride + dc[j]);
       const int slot = (wave * 2 + j) * 512;  // bf16 elements: 64 lanes x 8
-      __builtin_amdgcn_global_load_lds((gptr_t)(kb + off), (lptr_t)(dK + slot), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gptr_t)(vb + off), (lptr_t)(dV + slot), 16, 0, 0);
+      // buffer_load ... lds, not global_load_lds: keeps hipcc's counted lgkmcnt
+      // waits on the fragment reads
+      buffer_load_lds16(rsQ, (lptr_t)(dK + slot), off, 2 * H * HD);
+      buffer_load_lds16(rsQ, (lptr_t)(dV + slot), off, 4 * H * HD);
     }
   };
   dma(0, 0);
@@ -1134,6 +1136,8 @@ int veon_vit_attention(const void* qkv_bf16, const float* bias,
   if (B <= 0 || T <= 0 || H <= 0 || head_dim != HD || !qkv_bf16 || !out_bf16)
     return VEON_ERR_BAD_ARG;
   if (!al16(qkv_bf16) || !al16(out_bf16)) return VEON_ERR_BAD_ARG;
+  // the K/V DMA addresses an image's rows with 32-bit byte offsets
+  if ((int64_t)T * 3 * H * HD * 2 >= (1ll << 31)) return VEON_ERR_BAD_ARG;
   const dim3 grid((unsigned)((T + 4 * AQ - 1) / (4 * AQ)), (unsigned)H, (unsigned)B);
 #define VEON_LAUNCH_ATT(BIAS)                                                  \
   hipLaunchKernelGGL((k_attention<BIAS>), grid, dim3(256), 0,                  \
