@@ -16,6 +16,10 @@ from . import half as _half
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libveon_hip.so')
 LIB_PATHS = {'bf16': LIB_PATH, 'fp16': os.path.join(_HERE, 'libveon_hip_f16.so')}
+# tools/lib_ab.py only: time another BUILD of the bf16 library in the same process tree
+# (same-box A/B of kernel changes); never set in production
+if os.environ.get('VEON_HIP_LIB'):
+    LIB_PATHS['bf16'] = os.environ['VEON_HIP_LIB']
 _libs = {}  # flavour -> loaded library
 _lib = None
 

@@ -306,9 +306,11 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv3d_k3_ax(
   // turns every counted s_waitcnt lgkmcnt(N) of the fragment pipeline below into
   // lgkmcnt(0) ("pending flat").  Per-lane 32-bit BYTE offsets in VGPRs, the slab's
   // tap offset in an SGPR (the launcher checks the extents: < 2^31 elements).  The
-  // activation descriptor starts ((Yp + 1) Xp + 1) rows before `in` (inside the
+  // activation descriptor starts ((Yp + 1) Xp + 2) rows before `in` (inside the
   // guard rows), so that the most negative tap offset is still a positive offset.
-  const int abias = ((Yp + 1) * Xp + 1) * Cin;
+  // (the slab starts one row before the tile, m0 - 1: that row is part of the bias
+  // too, so that the per-lane offsets and the tap offsets are all non-negative)
+  const int abias = ((Yp + 1) * Xp + 2) * Cin;
   const rsrc_t rsA = make_rsrc(in - abias);
   const rsrc_t rsW = make_rsrc(W);
   int srcA[AP], srcW[WP];
@@ -316,7 +318,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv3d_k3_ax(
   for (int j = 0; j < AP; ++j) {
     const int r = (wave + j * NW) * 8 + (lane >> 3);
     const int c = (lane & 7) ^ (r & 7);
-    srcA[j] = 2 * ((m0 - 1 + r) * Cin + c * 8);
+    srcA[j] = 2 * ((m0 + r) * Cin + c * 8);
   }
 #pragma unroll
   for (int j = 0; j < WP; ++j) {
@@ -332,7 +334,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv3d_k3_ax(
     bf16_t* dA = smem + (g & 1) * A_ELEMS;
     const int zy = g / cpk, cc = (g - zy * cpk) * CBK;
     const int dz = kd == 3 ? zy / 3 - 1 : 0, dy = zy % 3 - 1;
-    const int ao = 2 * (((dz * Yp + dy) * Xp) * Cin + cc + abias);
+    const int ao = 2 * (((dz * Yp + dy) * Xp - 1) * Cin + cc + abias);
 #pragma unroll
     for (int j = 0; j < AP; ++j)
       if (wave + j * NW < APIECES)  // wave-uniform
@@ -818,8 +820,9 @@ static int conv_k3_impl(int kd, const void* in_padded, const void* w_bf16,
   bf16_t* O = static_cast<bf16_t*>(out_padded);
   const int planes = B * (Z + 2 * pz);
   // the slab-sharing kernel addresses activations and weights by 32-bit offsets
-  const bool fits32 = (M + 2 * veon_conv3d_guard_rows(Y, X)) * Cin < 0x7fffffffLL &&
-                      (int64_t)Cout * 9 * kd * Cin < 0x7fffffffLL;
+  // k_conv3d_k3_ax addresses both operands with 32-bit BYTE offsets (bf16: 2^30 elements)
+  const bool fits32 = (M + 2 * veon_conv3d_guard_rows(Y, X)) * Cin < 0x3fffffffLL &&
+                      (int64_t)Cout * 9 * kd * Cin < 0x3fffffffLL;
 #define VEON_LAUNCH_CONV(WM, WN, MT, ACT, RESID)                              \
   do {                                                                         \
     constexpr int ldsx =                                                       \
