@@ -442,9 +442,15 @@ def bev_pool_v2_prepared(depth, feat, pre, bev_feat_shape, out=None):
                           attach=False, counts=pre.counts)
     if out is None:
         out = torch.empty((B, C, Z, Y, X), dtype=torch.float32, device=dev)
+    # The interval count is unknown on the host here (the buffers are capacity-sized);
+    # the launcher only uses it to pick the LDS tile width (32 or 64 intervals per
+    # pass; either is correct).  Passing the capacity always selected the wide, slower
+    # variant (42 vs 35 us at S2): estimate it instead -- about 0.3 intervals per
+    # frustum point on nuScenes-like rigs (S2: 72.7 k of 249 k, SV: 342 k of 1.49 M).
+    n_est = max(1, int(0.3 * pre.interval_starts.numel()))
     with _lib.on_device(dev):
         st = _lib.lib().veon_bev_pool_v2_fwd_fused_ex(
-            C, pre.interval_starts.numel(), B, Z * Y * X, _lib.ptr(depth),
+            C, n_est, B, Z * Y * X, _lib.ptr(depth),
             _lib.ptr(feat), _feat_code(feat), _lib.ptr(pre.ranks_depth),
             _lib.ptr(pre.ranks_feat), _lib.ptr(pre.ranks_bev),
             _lib.ptr(pre.interval_starts), _lib.ptr(pre.interval_lengths),
