@@ -93,6 +93,10 @@ def parse():
     return p.parse_args()
 
 
+def solo_rank(world, rank):
+    return world == 1 and rank == 0
+
+
 def algorithmic_bytes(n_cams, hf, wf, C, D, p_kept, n_intervals, n_vox, batch=1,
                       feat_bytes=4, out_bytes=4, out_div=1):
     """feat once + depth once + 3 rank arrays + 2 interval arrays
@@ -508,6 +512,35 @@ def main():
         except Exception as e:  # report, do not hide
             print('per-call leg failed: %r' % (e,), file=sys.stderr)
 
+    # ---- backward leg (row a10; training only): the op's backward on a channels-last
+    # out_grad (what the reference's op receives, bev_pool.py:43-83) and the drop-in's
+    # whole backward from a (B,C,Z,Y,X) out_grad (+ its layout copy)
+    backward = None
+    if solo_rank(world, rank) and args.workload == 'S2' and args.shard == 'replicas':
+        try:
+            og_cl = torch.randn((1, Z, Y, X, C), device=dev)
+            og_cf = og_cl.permute(0, 4, 1, 2, 3).contiguous()
+            args_b = (vt.ranks_bev, depth5, feat_nhwc, vt.ranks_feat, vt.ranks_depth)
+            t_k = event_ms(lambda: bp._backward_impl(og_cl, *args_b), 50, warm=5)
+            t_f = event_ms(lambda: bp._backward_impl(
+                og_cf.permute(0, 2, 3, 4, 1).contiguous(), *args_b), 50, warm=5)
+            alg_b = (4 * n_int * C + 4 * n_cams * hf * wf * C + 4 * n_cams * D * hf * wf +
+                     4 * 3 * p_kept + 8 * n_int +
+                     4 * n_cams * hf * wf * C + 4 * n_cams * D * hf * wf)
+            backward = {
+                'what': 'bev_pool_v2 backward at S2 (depth.grad + feat.grad): QuickCumsumCuda.'
+                        'backward as the reference structures it (stable sort by ranks_feat + '
+                        'run lengths in torch, then the HIP grad kernel), HIP events',
+                'op_ms': round(t_k, 5), 'with_layout_copy_ms': round(t_f, 5),
+                'algorithmic_bytes': alg_b,
+                'achieved_GBps': round(alg_b / (t_k * 1e-3) / 1e9, 1),
+                'note': 'out_grad rows of the occupied voxels + depth + feat + ranks read, '
+                        'both gradients written; the (B,C,Z,Y,X) -> channels-last copy of '
+                        'out_grad (205 MB read + written, as the reference does) dominates '
+                        'the drop-in\'s backward'}
+        except Exception as e:  # report, do not hide
+            print('backward leg failed: %r' % (e,), file=sys.stderr)
+
     alg = algorithmic_bytes(n_cams, hf, wf, C, D, p_kept, n_int, Z * Y * X)
     achieved = alg / (kernel_ms * 1e-3) / 1e9
     ms_per_step = elapsed / args.steps * 1e3
@@ -564,6 +597,8 @@ def main():
         result['roofline']['placed'] = placed
     if percall is not None:
         result['percall_prepare'] = percall
+    if backward is not None:
+        result['backward'] = backward
     if solo and not args.no_sv and args.workload == 'S2':
         try:
             with torch.no_grad():

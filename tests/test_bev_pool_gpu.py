@@ -513,3 +513,39 @@ def test_feature_rows_transpose_kernel_equals_contiguous(dtype, B, N, C, H, W):
     assert torch.equal(bp._rows(other), other.contiguous())
     assert _lib.CALLS.get('veon_feat_nchw_to_nhwc', 0) == before + 1
     assert bp._rows(got) is got
+
+
+def test_backward_bit_exact_at_full_s2_size():
+    """Row a10 at BASELINE configs[1]'s full size (6 cams 256x704, D = 59, C = 80,
+    200x200x16 voxels, 109 k kept points): depth.grad and feat.grad of the HIP backward
+    (bev_pool_cuda.cu:67-121) equal the C oracle bit for bit, through the reference-layout
+    op and through the channels-first drop-in (out_grad arrives as (B,C,Z,Y,X))."""
+    from tools._inputs import lift_case
+    cs = lift_case(synthetic.GRID_S2, (256, 704), 6, 80, 'cuda:0')
+    X, Y, Z = cs['gsize']
+    shape = (1, Z, Y, X, 80)
+    depth, feat = cs['depth'], cs['feat_nhwc']
+    rb, rd, rf, st, ln = (cs[k] for k in ('rb', 'rd', 'rf', 'st', 'ln'))
+    g = torch.Generator().manual_seed(3)
+    og = torch.randn(shape, generator=g)
+    want_dg, want_fg = helpers.oracle_backward(
+        og.numpy(), depth.cpu().numpy(), feat.cpu().numpy(), rd.cpu().numpy(),
+        rf.cpu().numpy(), rb.cpu().numpy())
+    d = depth.clone().requires_grad_()
+    f = feat.clone().requires_grad_()
+    out = QuickCumsumCuda.apply(d, f, rd, rf, rb, shape, st, ln)
+    out.backward(og.cuda())
+    assert np.array_equal(d.grad.cpu().numpy(), want_dg)
+    assert np.array_equal(f.grad.cpu().numpy(), want_fg)
+    d2 = depth.clone().requires_grad_()
+    f2 = feat.clone().requires_grad_()
+    out2 = bev_pool_v2(d2, f2, rd, rf, rb, shape, st, ln)
+    assert tuple(out2.shape) == (1, 80, Z, Y, X)
+    out2.backward(og.permute(0, 4, 1, 2, 3).contiguous().cuda())
+    assert np.array_equal(d2.grad.cpu().numpy(), want_dg)
+    assert np.array_equal(f2.grad.cpu().numpy(), want_fg)
+    # size-independent property: the backward is linear in out_grad
+    d3 = depth.clone().requires_grad_()
+    f3 = feat.clone().requires_grad_()
+    QuickCumsumCuda.apply(d3, f3, rd, rf, rb, shape, st, ln).backward(2.0 * og.cuda())
+    assert torch.equal(d3.grad, 2.0 * d.grad) and torch.equal(f3.grad, 2.0 * f.grad)
