@@ -620,14 +620,23 @@ def main():
             # throughput with TWO samples in flight (two independent instances, each
             # its own hipGraph, replayed alternately on two streams): the same work per
             # sample, a serving-style figure beside the sequential one above
-            from tools import pipeline2
+            # (a child process: in THIS process, with the S2 / per-call / VEON-B graphs
+            # and their streams alive, the same two instances overlap far less -- 6.5 vs
+            # 5.9 ms per sample -- for a reason not yet found)
             torch.cuda.empty_cache()
-            r2 = pipeline2.run('vitb', (256, 704), steps=20, dev=str(dev), n_flight=2)
+            cp = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'pipeline2.py'),
+                                 'vitb', '40', '--json'], stdout=subprocess.PIPE,
+                                stderr=subprocess.STDOUT, text=True, timeout=300)
+            line = [ln for ln in cp.stdout.splitlines() if ln.startswith('PIPELINE2 ')]
+            if not line:
+                raise RuntimeError('tools/pipeline2.py: ' + cp.stdout[-300:])
+            r2 = json.loads(line[0][len('PIPELINE2 '):])
             result['veonb']['two_in_flight'] = {
                 'ms_per_sample': round(r2['pipelined_ms'], 4),
                 'samples_per_s': round(1e3 / r2['pipelined_ms'], 2),
                 'sequential_ms_same_instances': round(r2['sequential_ms'], 4),
                 'outputs_equal_to_sequential': r2['outputs_equal'],
+                'measured_in': 'child process (python tools/pipeline2.py vitb 40 --json)',
                 'what': 'two independent path instances (own buffers, own hipGraph) '
                         'replayed alternately on two streams; per-sample latency is '
                         'higher, throughput is what is reported'}

@@ -71,6 +71,10 @@ def run(enc='vitb', size=(256, 704), steps=40, dev='cuda:0', n_flight=2):
 if __name__ == '__main__':
     enc = sys.argv[1] if len(sys.argv) > 1 else 'vitb'
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+    if '--json' in sys.argv:   # what bench.py's child process prints
+        import json
+        print('PIPELINE2 ' + json.dumps(run(enc, steps=steps, n_flight=2)), flush=True)
+        sys.exit(0)
     for nf in (2, 3):
         r = run(enc, steps=steps, n_flight=nf)
         print('%s 256x704: sequential %.3f ms/sample (%.1f samples/s) | %d in flight %.3f '
