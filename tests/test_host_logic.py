@@ -60,6 +60,10 @@ def test_half_flavour_switch():
     assert half.dtype() == torch.bfloat16 and _lib.lib().veon_half_mode() == 0
     with pytest.raises(ValueError):
         half.set_half_dtype(torch.float32)
+    # operands of the other flavour are refused, never reinterpreted
+    _lib.require_half(torch.zeros(2, dtype=torch.bfloat16), None)
+    with pytest.raises(_lib.VeonHipError):
+        _lib.require_half(torch.zeros(2, dtype=torch.float16))
 
 
 def test_ops_refuse_cpu_tensors():

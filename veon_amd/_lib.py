@@ -187,6 +187,19 @@ def require_device(*tensors):
     return dev
 
 
+def require_half(*tensors):
+    """Operands of the MFMA kernels must have THE half dtype of the process
+    (veon_amd/half.py) -- a module built under the other flavour holds packed
+    weights of the other type: raise, never reinterpret the bits."""
+    want = _half.dtype()
+    for t in tensors:
+        if t is not None and t.dtype != want:
+            raise VeonHipError(
+                'half-precision operand is %s but this process runs the %s flavour of the '
+                'library (VEON_HALF / veon_amd.half.set_half_dtype): build the module under '
+                'the flavour it is used with' % (t.dtype, _half.name()))
+
+
 def ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 

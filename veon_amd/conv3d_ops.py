@@ -81,7 +81,8 @@ def conv3d_k3(vol, w_packed, scale=None, shift=None, resid=None, relu=False,
     dev = _lib.require_device(vol.storage, w_packed)
     B, Cin, Z, Y, X = vol.shape
     Cout = w_packed.shape[0]
-    assert w_packed.dtype == _half.dtype() and w_packed.is_contiguous()
+    _lib.require_half(w_packed, vol.rows)
+    assert w_packed.is_contiguous()
     assert w_packed.numel() == Cout * 27 * Cin
     if out is None:
         out = vol.like(Cout)
@@ -247,7 +248,8 @@ def conv2d_k3(img, w_packed, scale=None, shift=None, resid=None, relu=False,
     dev = _lib.require_device(img.storage, w_packed)
     B, Cin, Y, X = img.shape
     Cout = w_packed.shape[0]
-    assert w_packed.dtype == _half.dtype() and w_packed.is_contiguous()
+    _lib.require_half(w_packed)
+    assert w_packed.is_contiguous()
     assert w_packed.numel() == Cout * 9 * Cin
     if out is None:
         out = PaddedImage(B, Cout, Y, X, dev)
@@ -269,7 +271,8 @@ def conv2d_k3s2(img, w_packed, scale=None, shift=None, out=None, act=None):
     dev = _lib.require_device(img.storage, w_packed)
     B, Cin, Y, X = img.shape
     Cout = w_packed.shape[0]
-    assert w_packed.dtype == _half.dtype() and w_packed.is_contiguous()
+    _lib.require_half(w_packed)
+    assert w_packed.is_contiguous()
     assert w_packed.numel() == Cout * 9 * Cin
     Yo, Xo = (Y + 1) // 2, (X + 1) // 2
     if out is None:
@@ -350,7 +353,8 @@ def tokens_to_image(rows, tokens_per_image, skip, h, w, s, C, out):
     of every image (class token) are passed over."""
     dev = _lib.require_device(rows, out.storage)
     B = out.shape[0]
-    assert rows.dtype == _half.dtype() and rows.is_contiguous() and rows.dim() == 2
+    _lib.require_half(rows)
+    assert rows.is_contiguous() and rows.dim() == 2
     assert out.shape == (B, C, s * h, s * w) and rows.shape[0] == B * tokens_per_image
     with _lib.on_device(dev):
         st = _lib.lib().veon_tokens_to_image(

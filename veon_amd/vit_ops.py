@@ -84,7 +84,7 @@ def linear(a, w, bias=None, epilogue=EPI_BF16, out=None, gamma=None):
     """a bf16 [M,K], w bf16 [N,K] (nn.Linear layout) -> bf16 [M,N].  ``gamma``
     (fp32 [N]) is the per-feature scale of the EPI_AFFINE* epilogues."""
     dev = _dev(a, w)
-    assert a.dtype == _half.dtype() and w.dtype == _half.dtype()
+    _lib.require_half(a, w)
     assert a.is_contiguous() and w.is_contiguous()
     K = a.shape[-1]
     M = a.numel() // K
@@ -125,7 +125,8 @@ def attention(qkv, num_heads, bias=None, out=None):
     B, T, three_d = qkv.shape
     H = num_heads
     hd = three_d // (3 * H)
-    assert qkv.dtype == _half.dtype() and qkv.is_contiguous()
+    _lib.require_half(qkv)
+    assert qkv.is_contiguous()
     if out is None:
         out = torch.empty((B, T, H * hd), dtype=_half.dtype(), device=dev)
     sb = sh = 0
