@@ -171,7 +171,10 @@ int veon_bev_pool_v2_fwd_maxpool(int c, int n_intervals, int batch, int Z, int Y
  * feat_elems: number of elements of `feat` (rows * c); must be < 2^31 (row offsets
  *   are 32-bit inside the kernels; every ranks_feat value must be a valid row).
  */
-/* experiment knob of tools/poolbench.py (ablations); 0 = production */
+/* experiment knob of tools/poolbench.py / tools/xcd_order_ab.py; 0 = production.
+ * bits 0-3: ablations of the row max-pool kernel (results invalid); bit 4: tile =
+ * blockIdx instead of the XCD-grouped tile order; bits 8-11: (lg + 1) forces runs of
+ * 2^lg tiles per XCD -- the order never changes a result. */
 void veon_pool_debug_set(int flags);
 /* tuning knobs of the row max-pool kernel (0 = built-in default): worker
  * workgroups, longest cold list, longest warm list */
