@@ -810,6 +810,55 @@ static int conv_k3_impl(int kd, const void* in_padded, const void* w_bf16,
   // experiment knob (tools/dpt_probe2.py): bits 8..15 of veon_conv_debug_set force the
   // tile height (mt) of the 128- and 64-feature tile classes
   if (((g_conv_abl >> 8) & 0xff) != 0 && !is_wide && !is_mid) mt = (g_conv_abl >> 8) & 0xff;
+  // Under-filled grids (end of round 2, tools/conv_tile_sweep.py).  The choice above
+  // minimises rounds x rows and assumes the grid fills the chip; the small convs of
+  // the 256x704 path do not (HSA 384 -> 384 on 6 x 16 x 44 pixels: 90 tiles of
+  // 128 x 192; the DPT stride-2 conv 768 -> 768: 48 tiles of 192 x 256 on 256 CUs), and
+  // then a SMALLER tile is faster because a workgroup's k-loop is serial: 46 -> 35 us
+  // and 118 -> 69 us.  For those grids every instantiated tile is priced with
+  //   T = k-steps x max(floor, share x max(MFMA time / 0.6, LDS-DMA bytes / 45 GB/s))
+  // (floor 0.45 us = one DMA round trip per k-step; share = tiles per CU, whole
+  // rounds for the one-workgroup-per-CU tiles), which reproduces the sweep within
+  // ~15 %, and the cheapest wins.
+  {
+    const int64_t rows0 = wm * 16 * mt;
+    const int64_t tiles0 = ((active + rows0 - 1) / rows0 + B) * ((Cout + 64 * wn - 1) / (64 * wn));
+    if (tiles0 * 4 < 3 * kNumCU) {
+      static const Tile all[] = {{3, 4, 7}, {4, 4, 4}, {4, 4, 3}, {4, 3, 3}, {4, 3, 2}, {4, 2, 4},
+                                 {4, 2, 3}, {4, 2, 2}, {4, 2, 1}, {8, 1, 2}, {8, 1, 1}};
+      const int cmax = (int)((Cout + 63) / 64) * 64;
+      const double ksteps = 9.0 * kd * (Cin / CBK);
+      const double arow = stride == 1 ? 1.0 / 3.0 : 1.0;   // slab shared by three x-taps
+      double bestT = -1.0;
+      for (const Tile& t : all) {
+        const int r = t.wm * 16 * t.mt, c = 64 * t.wn;
+        if (c > cmax && t.wn > 1) continue;
+        const int lds_t = 2 * (r + 8 + c) * CBK * (int)sizeof(bf16_t);
+        if (lds_t > 160 * 1024) continue;
+        const double tiles = (double)(((active + r - 1) / r + B) * ((Cout + c - 1) / c));
+        const bool one_per_cu = lds_t > 80 * 1024;
+        double share = tiles / kNumCU;
+        if (one_per_cu) share = (double)((int64_t)((tiles + kNumCU - 1) / kNumCU));
+        if (share < 1.0) share = 1.0;
+        const double mfma = r * (double)c * 128.0 / 9.8e6 / 0.6;
+        const double dma = (arow * r + c) * 128.0 / 45.0e3;
+        double step = share * (mfma > dma ? mfma : dma);
+        if (step < 0.45) step = 0.45;
+        const double T = ksteps * step;
+        if (bestT < 0 || T < bestT) {
+          bestT = T;
+          wm = t.wm; wn = t.wn; mt = t.mt;
+        }
+      }
+    }
+  }
+  // experiment knob (tools/conv_tile_sweep.py): bits 16..27 of veon_conv_debug_set force
+  // the whole tile (wm, wn, mt: four bits each; must be one of the instantiated shapes)
+  if (((g_conv_abl >> 16) & 0xfff) != 0) {
+    wm = (g_conv_abl >> 16) & 15;
+    wn = (g_conv_abl >> 20) & 15;
+    mt = (g_conv_abl >> 24) & 15;
+  }
   const int bm = wm * 16 * mt;
   const int64_t ncol = (Cout + 64 * wn - 1) / (64 * wn);
   const dim3 grid((unsigned)ncol, (unsigned)((M + bm - 1) / bm));
