@@ -492,6 +492,11 @@ int veon_conv3d_k3_bf16(const void *in_padded, const void *w_bf16,
 /* experiment knob of tools/body_bench.py (ablations of the conv kernels' loads;
  * non-zero flags give WRONG results): 0 = normal. */
 void veon_conv_debug_set(int flags);
+/* Host-only: the (rows | cols << 16) tile the conv launcher picks for a problem
+ * (kd = 3: veon_conv3d_k3_bf16 on B x Z x Y x X voxels; kd = 1: the 2-D convs on
+ * B x Y x X output pixels, stride 1 or 2); -1 for an unsupported shape.  Lets the CPU
+ * tests pin the selection rule (csrc/conv3d.hip: conv_pick_tile). */
+int veon_conv_tile_choice(int kd, int B, int Z, int Y, int X, int Cin, int Cout, int stride);
 int veon_conv2d_k3_bf16(const void *in_padded, const void *w_bf16,
                         const float *scale, const float *shift,
                         const void *resid_padded, void *out_padded, int B, int Y,

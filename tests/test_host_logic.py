@@ -341,3 +341,21 @@ def test_hsa_network_matches_reference_vectors():
     assert torch.allclose(cb, t['convblock_out'], atol=1e-5)
     assert torch.allclose(attns, t['attns'], atol=2e-4, rtol=1e-4)
     assert torch.allclose(supp, t['supp'], atol=1e-5)
+
+
+def test_conv_tile_choice_rule():
+    """The conv launcher's tile (csrc/conv3d.hip: conv_pick_tile), host-only: big grids
+    keep the measured choices, under-filled grids take the small tiles the sweep found
+    (profiles/r02_conv_tile_sweep.txt)."""
+    lib = _lib.lib()
+
+    def tile(kd, B, Z, Y, X, Cin, Cout, stride=1):
+        v = lib.veon_conv_tile_choice(kd, B, Z, Y, X, Cin, Cout, stride)
+        return (v & 0xffff, v >> 16)
+    assert tile(3, 1, 8, 100, 100, 256, 256) == (336, 256)       # the Conv3d body
+    assert tile(1, 6, 1, 9, 25, 768, 768, 2) == (64, 128)        # DPT stride-2 conv: 48 -> 204 tiles
+    assert tile(1, 6, 1, 32, 88, 384, 384) == (192, 192)         # HSA at 256x704: grid fills
+    assert tile(1, 6, 1, 16, 44, 384, 384)[0] <= 128             # a quarter of that: small tile
+    assert tile(1, 6, 1, 144, 400, 128, 64)[1] == 64             # 64-feature class
+    assert tile(1, 6, 1, 72, 200, 128, 128) == (128, 128)        # large 128-feature conv
+    assert lib.veon_conv_tile_choice(1, 6, 1, 9, 25, 100, 128, 1) == -1   # Cin % 64

@@ -81,6 +81,7 @@ _SIGNATURES = {
     'veon_vit_block': (_ci, [_vp, _vp, _vp, _i64, _i64, _vp, _i64] + [_ci] * 4 + [_vp]),
     'veon_conv3d_guard_rows': (_i64, [_ci, _ci]),
     'veon_conv_debug_set': (None, [_ci]),
+    'veon_conv_tile_choice': (_ci, [_ci] * 8),
     'veon_conv3d_k3_bf16': (_ci, [_vp] * 6 + [_ci] * 7 + [_vp]),
     'veon_conv2d_k3_bf16': (_ci, [_vp] * 6 + [_ci] * 6 + [_vp]),
     'veon_conv2d_k3s2_bf16': (_ci, [_vp] * 6 + [_ci] * 6 + [_vp]),

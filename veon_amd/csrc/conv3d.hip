@@ -752,25 +752,14 @@ int64_t veon_conv3d_guard_rows(int Y, int X) {
 
 static int g_conv_abl = 0;
 
-static int conv_k3_impl(int kd, const void* in_padded, const void* w_bf16,
-                        const float* scale, const float* shift,
-                        const void* resid_padded, void* out_padded, int B, int Z,
-                        int Y, int X, int Cin, int Cout, int relu, void* stream,
-                        int stride = 1, int Yin = 0, int Xin = 0) {
-  // Y, X: the OUTPUT grid; Yin, Xin: the input image of a strided 2-D conv
-  if (stride == 1) { Yin = Y; Xin = X; }
-  if (stride < 1 || stride > 2 || (stride == 2 && kd != 1) || Yin <= 0 || Xin <= 0)
-    return VEON_ERR_BAD_ARG;
-  const int pz = kd == 3 ? 1 : 0;  // z halo planes on each side
-  if (B <= 0 || Z <= 0 || Y <= 0 || X <= 0 || Cin <= 0 || Cout <= 0 ||
-      Cin % CBK != 0 || Cout % 8 != 0 || !in_padded || !w_bf16 || !out_padded)
-    return VEON_ERR_BAD_ARG;
-  if (!al16(in_padded) || !al16(w_bf16) || !al16(out_padded) ||
-      (scale && !al16(scale)) || (shift && !al16(shift)) ||
-      (resid_padded && !al16(resid_padded)))
-    return VEON_ERR_BAD_ARG;
+struct ConvTile { int wm, wn, mt; };
+
+// Tile of the 3x3(x3) conv launch for one problem (host-only logic, also exported as
+// veon_conv_tile_choice so that the CPU tests pin it).  Y, X: the output grid.
+static ConvTile conv_pick_tile(int kd, int B, int Z, int Y, int X, int Cin, int Cout,
+                               int stride) {
+  const int pz = kd == 3 ? 1 : 0;
   const int64_t M = (int64_t)B * (Z + 2 * pz) * (Y + 2) * (X + 2);
-  if (M > 0x3fffffffLL) return VEON_ERR_BAD_ARG;
   // Tile choice.  256 features wide when the layer has them (the activation
   // slab is then fetched once, not once per 128-feature column); the height is
   // the candidate with the fewest rounds x rows over the 256 CUs, counting only
@@ -859,6 +848,30 @@ static int conv_k3_impl(int kd, const void* in_padded, const void* w_bf16,
     wn = (g_conv_abl >> 20) & 15;
     mt = (g_conv_abl >> 24) & 15;
   }
+  return ConvTile{wm, wn, mt};
+}
+
+static int conv_k3_impl(int kd, const void* in_padded, const void* w_bf16,
+                        const float* scale, const float* shift,
+                        const void* resid_padded, void* out_padded, int B, int Z,
+                        int Y, int X, int Cin, int Cout, int relu, void* stream,
+                        int stride = 1, int Yin = 0, int Xin = 0) {
+  // Y, X: the OUTPUT grid; Yin, Xin: the input image of a strided 2-D conv
+  if (stride == 1) { Yin = Y; Xin = X; }
+  if (stride < 1 || stride > 2 || (stride == 2 && kd != 1) || Yin <= 0 || Xin <= 0)
+    return VEON_ERR_BAD_ARG;
+  const int pz = kd == 3 ? 1 : 0;  // z halo planes on each side
+  if (B <= 0 || Z <= 0 || Y <= 0 || X <= 0 || Cin <= 0 || Cout <= 0 ||
+      Cin % CBK != 0 || Cout % 8 != 0 || !in_padded || !w_bf16 || !out_padded)
+    return VEON_ERR_BAD_ARG;
+  if (!al16(in_padded) || !al16(w_bf16) || !al16(out_padded) ||
+      (scale && !al16(scale)) || (shift && !al16(shift)) ||
+      (resid_padded && !al16(resid_padded)))
+    return VEON_ERR_BAD_ARG;
+  const int64_t M = (int64_t)B * (Z + 2 * pz) * (Y + 2) * (X + 2);
+  if (M > 0x3fffffffLL) return VEON_ERR_BAD_ARG;
+  const ConvTile tile = conv_pick_tile(kd, B, Z, Y, X, Cin, Cout, stride);
+  const int wm = tile.wm, wn = tile.wn, mt = tile.mt;
   const int bm = wm * 16 * mt;
   const int64_t ncol = (Cout + 64 * wn - 1) / (64 * wn);
   const dim3 grid((unsigned)ncol, (unsigned)((M + bm - 1) / bm));
@@ -930,6 +943,14 @@ static int conv_k3_impl(int kd, const void* in_padded, const void* w_bf16,
 }
 
 void veon_conv_debug_set(int flags) { g_conv_abl = flags; }
+
+int veon_conv_tile_choice(int kd, int B, int Z, int Y, int X, int Cin, int Cout, int stride) {
+  if ((kd != 1 && kd != 3) || B <= 0 || Z <= 0 || Y <= 0 || X <= 0 || Cin <= 0 || Cout <= 0 ||
+      Cin % CBK != 0 || stride < 1 || stride > 2)
+    return -1;
+  const ConvTile t = conv_pick_tile(kd, B, Z, Y, X, Cin, Cout, stride);
+  return (t.wm * 16 * t.mt) | ((64 * t.wn) << 16);
+}
 
 int veon_conv3d_k3_bf16(const void* in_padded, const void* w_bf16,
                         const float* scale, const float* shift,
