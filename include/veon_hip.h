@@ -171,6 +171,17 @@ int veon_bev_pool_v2_fwd_maxpool(int c, int n_intervals, int batch, int Z, int Y
  * feat_elems: number of elements of `feat` (rows * c); must be < 2^31 (row offsets
  *   are 32-bit inside the kernels; every ranks_feat value must be a valid row).
  */
+/*
+ * 2x2x2 block max of a (B,C,Z,Y,X) fp32 volume -> (B,C,Z/2,Y/2,X/2) fp32: the
+ * ds_feat step of LSSViewTransformerRaw.forward (view_transformer_raw.py:549-553:
+ * rearrange + max over the three block axes) as one streaming pass, for volumes that
+ * did not come out of the fused pool + max-pool kernel (the camera-sharded path: the
+ * block max follows the cross-rank sum).  planes = B * C; Z, Y, X even.  NaN
+ * propagates as in torch.amax.
+ */
+int veon_volume_maxpool2_f32(const float *in, float *out, int64_t planes, int Z, int Y,
+                             int X, void *stream);
+
 /* experiment knob of tools/poolbench.py / tools/xcd_order_ab.py; 0 = production.
  * bits 0-3: ablations of the row max-pool kernel (results invalid); bit 4: tile =
  * blockIdx instead of the XCD-grouped tile order; bits 8-11: (lg + 1) forces runs of

@@ -67,3 +67,26 @@ def test_image_subsample(Y, X, step):
     out = conv3d_ops.image_subsample(conv3d_ops.pack_image(x), step)
     got = conv3d_ops.unpack_image(out, torch.bfloat16)
     assert torch.equal(got, x[:, :, ::step, ::step])
+
+
+def test_volume_maxpool2_equals_torch_amax():
+    """veon_volume_maxpool2_f32 (the camera-sharded path's ds_feat step after the
+    cross-rank sum) against view + amax (view_transformer_raw.py:549-553), bit for bit,
+    NaN included; through VeonOccupancyPath._max_pool's dispatch."""
+    import ctypes
+    from veon_amd import _lib
+    g = torch.Generator().manual_seed(5)
+    for B, C, Z, Y, X in ((1, 7, 4, 6, 10), (2, 16, 16, 20, 200), (1, 64, 16, 200, 200)):
+        vol = torch.randn(B, C, Z, Y, X, generator=g).to(DEV)
+        vol[0, 0, 0, 0, 1] = float('nan')
+        vol[0, -1, -1, -1, -1] = float('-inf')
+        out = torch.empty(B, C, Z // 2, Y // 2, X // 2, device=DEV)
+        st = _lib.lib().veon_volume_maxpool2_f32(_lib.ptr(vol), _lib.ptr(out), B * C, Z, Y, X,
+                                                 _lib.stream_ptr(vol.device))
+        _lib.check(st, 'veon_volume_maxpool2_f32')
+        want = vol.view(B, C, Z // 2, 2, Y // 2, 2, X // 2, 2).amax(dim=(3, 5, 7))
+        assert torch.equal(torch.nan_to_num(out, nan=12345.0), torch.nan_to_num(want, nan=12345.0))
+        assert torch.isnan(out[0, 0, 0, 0, 0])
+    # odd extents are refused
+    assert _lib.lib().veon_volume_maxpool2_f32(_lib.ptr(vol), _lib.ptr(out), 1, 3, 4, 4,
+                                               ctypes.c_void_p(0)) != 0

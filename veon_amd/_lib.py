@@ -57,6 +57,7 @@ _SIGNATURES = {
     'veon_bev_pool_v2_fwd_maxpool_ex': (_ci, [_ci] * 9 + [_vp, _vp, _ci] + [_vp] * 7 + [_vp]),
     'veon_bev_pool_v2_fwd_maxpool_padded': (_ci, [_ci] * 9 + [_vp, _vp, _ci] + [_vp] * 7 + [_vp]),
     'veon_bev_pool_tile_voxels': (_ci, []),
+    'veon_volume_maxpool2_f32': (_ci, [_vp, _vp, _i64] + [_ci] * 3 + [_vp]),
     'veon_pool_debug_set': (None, [_ci]),
     'veon_pool_tune_set': (None, [_ci, _ci, _ci]),
     'veon_bev_pool_voxel_table_ints': (_i64, [_ci, _i64]),

@@ -699,6 +699,45 @@ __global__ __launch_bounds__(256) void k_feat_nchw_to_nhwc(const T* __restrict__
     if (p < HW && c < C) ob[(int64_t)p * C + c] = t[tx][r];
   }
 }
+// ---------------------------------------------------------------------------
+// (dz,dy,dx) = 2x2x2 block max of a (B,C,Z,Y,X) fp32 volume -> (B,C,Z/2,Y/2,X/2):
+// the ds_feat step of LSSViewTransformerRaw.forward (view_transformer_raw.py:549-553)
+// for volumes that could not go through the fused pool + max-pool kernel -- the
+// camera-sharded path, where the block max must follow the cross-rank sum (torch's
+// view + amax takes 1.2 ms on the 655 MB VEON volume; this is one streaming pass).
+// A lane owns one output voxel: four 8-byte loads (x pairs of two y rows of two z
+// planes), consecutive lanes consecutive x.  NaN propagates as in torch.amax.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float max_nan(float m, float v) {
+  return (v > m || v != v) ? v : m;
+}
+__global__ __launch_bounds__(256) void k_volume_maxpool2(const float* __restrict__ in,
+                                                         float* __restrict__ out,
+                                                         int64_t planes, int Z, int Y, int X) {
+  const int Zo = Z / 2, Yo = Y / 2, Xo = X / 2;
+  const int64_t total = planes * Zo * Yo * Xo;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int xo = (int)(i % Xo);
+  const int64_t r1 = i / Xo;
+  const int yo = (int)(r1 % Yo);
+  const int64_t r2 = r1 / Yo;
+  const int zo = (int)(r2 % Zo);
+  const int64_t p = r2 / Zo;
+  const float* base = in + ((p * Z + 2 * zo) * Y + 2 * yo) * (int64_t)X + 2 * xo;
+  float m = -__builtin_inff();
+#pragma unroll
+  for (int dz = 0; dz < 2; ++dz)
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy) {
+      const float* q = base + ((int64_t)dz * Y + dy) * X;
+      // X even: 2*xo keeps the 8-byte alignment of the row when the row start has it
+      const float a = __builtin_nontemporal_load(q), b = __builtin_nontemporal_load(q + 1);
+      m = max_nan(max_nan(m, a), b);
+    }
+  out[i] = m;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1085,6 +1124,19 @@ int veon_feat_nchw_to_nhwc(const void* in, void* out, int elem_bytes, int images
     hipLaunchKernelGGL(k_feat_nchw_to_nhwc<unsigned short>, grid, dim3(256), 0, s,
                        static_cast<const unsigned short*>(in),
                        static_cast<unsigned short*>(out), C, HW);
+  return launch_status();
+}
+
+int veon_volume_maxpool2_f32(const float* in, float* out, int64_t planes, int Z, int Y,
+                             int X, void* stream) {
+  // planes = B * C (every (b, c) volume is pooled on its own)
+  if (!in || !out || planes <= 0 || Z <= 0 || Y <= 0 || X <= 0 || (Z & 1) || (Y & 1) || (X & 1))
+    return VEON_ERR_BAD_ARG;
+  const int64_t total = planes * (Z / 2) * (Y / 2) * (X / 2);
+  const int64_t blocks = (total + 255) / 256;
+  if (blocks > 0x7fffffffLL) return VEON_ERR_BAD_ARG;
+  hipLaunchKernelGGL(k_volume_maxpool2, dim3((unsigned)blocks), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), in, out, planes, Z, Y, X);
   return launch_status();
 }
 
