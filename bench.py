@@ -12,13 +12,23 @@ voxels.  Inputs are resident in HBM before the timed region.  N>1: one process
 per GPU (torchrun), independent samples per rank, no data-path collective
 ("weak" scaling); the wall time is the max over ranks.
 
+`--gpus N` with N > 1 and no launcher in the environment (WORLD_SIZE unset) starts
+the N ranks itself (`python -m torch.distributed.run --nproc-per-node N ...` as a
+child process, before anything touches the GPU) and exits with the child's code; a
+launcher whose world size differs from --gpus is an error.
+
 Rank 0 prints ONE JSON line.  `roofline` is the dominant kernel of the step
-(k_pool_fused_cf, HBM bound): algorithmic bytes / mean launch time from HIP
-events on the launch stream, into whatever buffer the allocator hands out (no
-placement search: `--placement` adds the tuned-placement figure as a secondary
-key).  `roofline.traffic` comes from two rocprofv3 --pmc passes run as child
-processes of this script (FETCH_SIZE, WRITE_SIZE; N=1 only).  At N=1 the line
-also carries
+(k_pool_fused_cf, HBM bound): algorithmic bytes / mean launch duration.  The
+duration in `frac` is the `rocprofv3 --kernel-trace --stats` average of a child
+process of THIS run (tools/pool_case.py ROOFLINE: the kernel round-robin into 8
+output allocations held at once, so the placement-dependent speed of one
+allocation -- DESIGN 4 -- averages out; `roofline.placement` says how many of the
+8 were in the fast mode); the stats CSV of that child is kept under
+gpurun_out/bench_evidence/ (copy it to profiles/ to commit it).  The same launch
+timed by HIP events on the launch stream in this process is the secondary key
+`kernel_ms_hip_events`.  `roofline.traffic` comes from two rocprofv3 --pmc passes
+run as child processes of this script (FETCH_SIZE, WRITE_SIZE; N=1 only).  At N=1
+the line also carries
   `sv`    the VEON-shaped lift (6 cams 512x1408, D=88, C=256): the fused forward
           (691.7 MB algorithmic) and the fused pool + 2x2x2 max-pool (118 MB fp32 /
           the Conv3d body's bf16 input), each with its own roofline numbers;
@@ -90,7 +100,60 @@ def parse():
                         'configs[2] names bf16, configs[4] fp16')
     p.add_argument('--no-pmc', action='store_true',
                    help='skip the rocprofv3 --pmc child passes (roofline.traffic = null)')
+    p.add_argument('--no-rocprof', action='store_true',
+                   help='skip the rocprofv3 --kernel-trace child (roofline from HIP events)')
+    p.add_argument('--evidence-dir', default=os.path.join(ROOT, 'gpurun_out', 'bench_evidence'),
+                   help='where the rocprofv3 kernel stats of the roofline child are kept')
+    p.add_argument('--dry-run', action='store_true',
+                   help='launch / rendezvous / timing protocol only, on the CPU with gloo '
+                        'and a sleep as the step: what the CPU tests drive (no GPU needed)')
     return p.parse_args()
+
+
+def launch_ranks(args):
+    """--gpus N > 1 without a launcher: start the N ranks (one process per GPU) as a
+    child `torch.distributed.run` and exit with its code.  Runs before anything
+    initialises the GPU in this process (importing torch does not), so no GPU
+    process is ever replaced or forked (tools/dist_test.sh:11-22 is the reference's
+    launcher of the same shape)."""
+    if args.gpus <= 1 or 'WORLD_SIZE' in os.environ or 'RANK' in os.environ:
+        return
+    import socket
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+           '--nproc-per-node', str(args.gpus), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', '4')
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def dry_run(args, rank, world):
+    """The N-rank protocol without a GPU: gloo rendezvous, W warm-up + K timed steps
+    of a 1 ms sleep between barriers, MAX over ranks, one JSON line from rank 0."""
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit('world size %d != --gpus %d' % (dist.get_world_size(), args.gpus))
+    elapsed = timed_steps(lambda: time.sleep(1e-3), args.steps, args.warmup, dist, 'cpu',
+                          rehearse=True, gpu=False)
+    if rank == 0:
+        print(json.dumps({
+            'metric': '6cam_lift_samples_per_sec', 'value': None, 'unit': 'samples/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(elapsed / args.steps * 1e3, 4), 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'dry_run': True,
+            'config': {'workload': 'dry run: 1 ms sleep per step, no GPU work',
+                       'parallelism': 'replicas x%d' % world}}), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
 
 
 def solo_rank(world, rank):
@@ -121,18 +184,19 @@ def event_ms(fn, iters, warm=5):
     return e0.elapsed_time(e1) / iters
 
 
-def timed_steps(run, steps, warmup, dist, dev, rehearse=False):
+def timed_steps(run, steps, warmup, dist, dev, rehearse=False, gpu=True):
     """W warm-up steps, then exactly K steps between barrier + synchronize on both
     sides; max over ranks."""
+    sync = torch.cuda.synchronize if gpu else (lambda: None)
     for _ in range(warmup):
         run()
     if dist is not None:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     for _ in range(steps):
         run()
-    torch.cuda.synchronize()
+    sync()
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
@@ -182,6 +246,71 @@ def pmc_traffic():
     return out, 'two rocprofv3 --pmc child passes of tools/pool_case.py in this run'
 
 
+def kernel_trace_stats(evidence_dir):
+    """`rocprofv3 --kernel-trace --stats -- python tools/pool_case.py ROOFLINE` as a
+    child of this run -> ({kernel-name: {'avg_ns', 'calls', 'per_buffer_us'}}, note).
+    The S2 kernel is launched round-robin into ROOFLINE_BUFFERS allocations, so launch
+    i (in start order) wrote buffer i % ROOFLINE_BUFFERS: `per_buffer_us` is the median
+    per allocation.  The child's *_kernel_stats.csv is copied to `evidence_dir`."""
+    exe = shutil.which('rocprofv3')
+    if exe is None:
+        return {}, 'rocprofv3 not on PATH'
+    from tools.pool_case import ROOFLINE_BUFFERS
+    tmp = tempfile.mkdtemp(prefix='veon_kt_', dir='/tmp')
+    env = dict(os.environ, TMPDIR='/tmp')
+    out = {}
+    try:
+        cmd = [exe, '--kernel-trace', '--stats', '--output-format', 'csv', '-d', tmp, '--',
+               sys.executable, os.path.join(ROOT, 'tools', 'pool_case.py'), 'ROOFLINE']
+        r = subprocess.run(cmd, cwd='/tmp', env=env, stdout=subprocess.PIPE,
+                           stderr=subprocess.STDOUT, timeout=300)
+        if r.returncode != 0:
+            return {}, 'rocprofv3 --kernel-trace exited %d' % r.returncode
+        stats = glob.glob(os.path.join(tmp, '**', '*kernel_stats.csv'), recursive=True)
+        trace = glob.glob(os.path.join(tmp, '**', '*kernel_trace.csv'), recursive=True)
+        if not stats or not trace:
+            return {}, 'rocprofv3 wrote no kernel stats'
+        for row in csv.DictReader(open(stats[0])):
+            out[row['Name']] = {'avg_ns': float(row['AverageNs']), 'calls': int(row['Calls'])}
+        per = {}
+        for row in csv.DictReader(open(trace[0])):
+            per.setdefault(row['Kernel_Name'], []).append(
+                (int(row['Start_Timestamp']), int(row['End_Timestamp'])))
+        for name, spans in per.items():
+            if 'k_pool_fused_cf' not in name or name not in out:
+                continue
+            spans.sort()
+            med = []
+            for b in range(ROOFLINE_BUFFERS):
+                d = sorted(e - st for st, e in spans[b::ROOFLINE_BUFFERS])
+                med.append(round(d[len(d) // 2] / 1e3, 2))
+            out[name]['per_buffer_us'] = med
+        try:
+            os.makedirs(evidence_dir, exist_ok=True)
+            shutil.copy(stats[0], os.path.join(evidence_dir, 'roofline_kernel_stats.csv'))
+        except OSError:
+            pass
+    except (subprocess.TimeoutExpired, OSError, KeyError, ValueError) as e:
+        return {}, 'rocprofv3 child failed: %r' % (e,)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return out, ('rocprofv3 --kernel-trace --stats child of this run '
+                 '(python tools/pool_case.py ROOFLINE)')
+
+
+def rocprof_of(kt, needle):
+    """(average ms, calls, entry) of the first traced kernel whose name contains
+    `needle`, or (None, 0, None)."""
+    for k, c in kt.items():
+        if needle in k:
+            return c['avg_ns'] * 1e-6, c['calls'], c
+    return None, 0, None
+
+
+# the two placement modes of the S2 kernel (DESIGN 4): ~34 us and ~41 us
+PLACEMENT_THRESHOLD_US = 37.5
+
+
 def traffic_of(pmc, needle):
     """WRITE_SIZE + 2 x FETCH_SIZE in bytes for the first kernel whose name
     contains `needle` (MI355X_MICROARCH.md: FETCH_SIZE under-reports wide reads by
@@ -195,7 +324,7 @@ def traffic_of(pmc, needle):
 # ---------------------------------------------------------------------------
 # sub-objects
 # ---------------------------------------------------------------------------
-def sv_subobject(dev, pmc):
+def sv_subobject(dev, pmc, kt):
     """The VEON-shaped lift (SV): fused forward and fused pool + max-pool kernels,
     each with its own algorithmic bytes (never mixed)."""
     from tools._inputs import lift_case
@@ -232,10 +361,15 @@ def sv_subobject(dev, pmc):
                        'cached ranks' % (D, C, X, Y, Z),
            'points_kept': p, 'intervals': i}
     for key, (kname, what, alg, fn) in cases.items():
-        ms = event_ms(fn, 50)
+        ev_ms = event_ms(fn, 50)
+        rp_ms, calls, _ = rocprof_of(kt, kname)
+        ms = rp_ms if rp_ms is not None else ev_ms
         gbs = alg / (ms * 1e-3) / 1e9
         res[key] = {'kernel': kname.split('<')[0], 'what': what, 'bound': 'hbm',
                     'algorithmic_bytes': alg, 'kernel_ms': round(ms, 5),
+                    'kernel_ms_source': 'rocprofv3' if rp_ms is not None else 'hip_events',
+                    'kernel_ms_rocprof': None if rp_ms is None else round(rp_ms, 5),
+                    'rocprof_calls': calls, 'kernel_ms_hip_events': round(ev_ms, 5),
                     'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                     'frac': round(gbs / HBM_PEAK_GBS, 4),
                     'traffic': traffic_of(pmc, kname)}
@@ -292,16 +426,29 @@ def bench_hotpath(args, rank, world, dev, dist):
         net, images, geom = r['net'], r['images'], r['geom']
         rd = torch.bfloat16 if os.environ.get('VEON_REDUCE_DTYPE', 'bf16') == 'bf16' else None
 
-        def step():
-            return net.forward_camera_sharded(images, geom, reduce_dtype=rd,
-                                              reduce=args.reduce)
+        launch = 'eager'
+        step = None
+        if not args.no_graph:
+            try:
+                from veon_amd.models.veon_occ import CameraShardedStep
+                with torch.no_grad():
+                    sharded = CameraShardedStep(net, images, geom, reduce_dtype=rd,
+                                                reduce=args.reduce)
+                step = lambda: sharded(images)  # noqa: E731
+                launch = sharded.launch
+            except Exception as e:  # report, do not hide
+                print('sharded graph segments failed (%r); eager' % (e,), file=sys.stderr)
+        if step is None:
+            def step():
+                return net.forward_camera_sharded(images, geom, reduce_dtype=rd,
+                                                  reduce=args.reduce)
         with torch.no_grad():
             el = timed_steps(step, args.steps, args.warmup, dist, dev)
         ms = el / args.steps * 1e3
         stages = {k: round(v, 3) for k, v in r.items() if k.endswith('_ms')}
         tf = 8 * 2.0 * 8 * 100 * 100 * 256 * 256 * 27 / (r['body_ms'] * 1e-3) / 1e12
-        launch = 'eager; %s of the un-pooled volume in %s' % (
-            'all-reduce' if args.reduce == 'allreduce' else
+        launch = '%s; %s of the un-pooled volume in %s' % (
+            launch, 'all-reduce' if args.reduce == 'allreduce' else
             'reduce-scatter (channel slices) + sharded max-pool + all-gather',
             'bf16' if rd is not None else 'fp32')
         value, scaling = 1e3 / ms, 'strong'
@@ -329,9 +476,14 @@ def bench_hotpath(args, rank, world, dev, dist):
 
 def main():
     args = parse()
+    launch_ranks(args)   # --gpus N > 1 without a launcher: never returns
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
+    if world != args.gpus:
+        raise SystemExit('bench.py: launcher world size %d != --gpus %d' % (world, args.gpus))
+    if args.dry_run:
+        return dry_run(args, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a ROCm device (no CPU fallback)')
     # rehearsal knobs for a ONE-GPU box (never set by the driver): all ranks on
@@ -350,6 +502,9 @@ def main():
         else:
             dist.init_process_group('nccl', rank=rank, world_size=world,
                                     device_id=dev)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit('bench.py: process group of %d ranks != --gpus %d'
+                             % (dist.get_world_size(), args.gpus))
 
     from veon_amd import _lib, synthetic
     from veon_amd.models import build_neck
@@ -461,7 +616,18 @@ def main():
                                      vt.ranks_feat, vt.ranks_bev,
                                      vt.interval_starts, vt.interval_lengths,
                                      shape, _lib.LAYOUT_BCZYX, out=out)
-        kernel_ms = event_ms(kernel_only, kiters, warm=10)
+        # round-robin into 8 allocations held at once, like the rocprofv3 child: the
+        # speed of this kernel depends on where its output volume lies
+        from tools.pool_case import ROOFLINE_BUFFERS
+        bufs = [torch.empty((1, C, Z, Y, X), dtype=torch.float32, device=dev)
+                for _ in range(ROOFLINE_BUFFERS)] if not bp._rows_ok(C) else [None]
+        turn = [0]
+
+        def kernel_rr():
+            turn[0] += 1
+            return kernel_only(bufs[turn[0] % len(bufs)])
+        kernel_ms = event_ms(kernel_rr, kiters, warm=10)
+        del bufs
         placed = None
         if args.placement and args.shard == 'replicas':
             from veon_amd import placement
@@ -548,9 +714,25 @@ def main():
 
     solo = rank == 0 and world == 1
     pmc, pmc_src = ({}, 'not collected')
+    kt, kt_src = ({}, 'not collected')
     if solo and not args.no_pmc:
         pmc, pmc_src = pmc_traffic()
+    if solo and not args.no_rocprof and args.workload == 'S2':
+        torch.cuda.empty_cache()
+        kt, kt_src = kernel_trace_stats(args.evidence_dir)
     kname = 'k_pool_fused_cf' if not bp._rows_ok(C) else 'k_rows_fused_cf'
+    rp_ms, rp_calls, rp_entry = rocprof_of(kt, kname)
+    events_ms = kernel_ms
+    if rp_ms is not None:   # the reproducible number: frac is computed from it
+        kernel_ms = rp_ms
+        achieved = alg / (kernel_ms * 1e-3) / 1e9
+    placement = None
+    if rp_entry is not None and rp_entry.get('per_buffer_us'):
+        per = rp_entry['per_buffer_us']
+        fast = sum(1 for v in per if v < PLACEMENT_THRESHOLD_US)
+        placement = {'buffers': len(per), 'fast': fast, 'median_us_per_buffer': per,
+                     'threshold_us': PLACEMENT_THRESHOLD_US,
+                     'mode': 'fast' if fast == len(per) else 'slow' if fast == 0 else 'mixed'}
     result = {
         'metric': '6cam_lift_samples_per_sec',
         'value': round(value, 2),
@@ -588,7 +770,14 @@ def main():
             'traffic_source': pmc_src,
             'algorithmic_bytes': alg,
             'kernel_ms': round(kernel_ms, 5),
+            'kernel_ms_source': 'rocprofv3' if rp_ms is not None else 'hip_events',
+            'kernel_ms_rocprof': None if rp_ms is None else round(rp_ms, 5),
+            'rocprof_calls': rp_calls, 'rocprof_source': kt_src,
+            'kernel_ms_hip_events': round(events_ms, 5),
+            'frac_hip_events': round(alg / (events_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             'kernel_launches_timed': kiters,
+            'placement_mode': placement['mode'] if placement else None,
+            'placement': placement,
         },
     }
     if placed is not None:
@@ -602,7 +791,7 @@ def main():
     if solo and not args.no_sv and args.workload == 'S2':
         try:
             with torch.no_grad():
-                result['sv'] = sv_subobject(dev, pmc)
+                result['sv'] = sv_subobject(dev, pmc, kt)
         except Exception as e:  # report, do not hide
             print('sv sub-object failed: %r' % (e,), file=sys.stderr)
     if solo and not args.no_veonb and args.workload == 'S2':
@@ -706,16 +895,40 @@ def cpu_baseline(args, grid, input_size, n_cams, C, rig, depth5, feat5):
         el = time.perf_counter() - t0
         if el > args.cpu_seconds or n >= 400:
             break
+    # the per-call step VEON runs (accelerate=False): geometry + prepare + pool each
+    # call, same thread count, a bounded sample
+    m, t1 = 0, time.perf_counter()
+    while True:
+        lss_torch.lift(fr, (lower, interval, gsize), cams, d, f)
+        m += 1
+        el2 = time.perf_counter() - t1
+        if el2 > max(args.cpu_seconds * 0.5, 2.0) or m >= 200:
+            break
     torch.set_num_threads(default_threads)
     return {
         'value': round(n / el, 3), 'unit': 'samples/s', 'cores': best,
+        'host_cores': ncpu, 'cpu_model': cpu_model(),
         'kind': 'port',
         'sample': '%d iterations (%.1f s) of oracle.lss_torch.lift with cached '
                   'ranks on the %s workload, torch %d threads (best of %s by a 1.5 s '
                   'probe each: %s samples/s), fp32'
                   % (n, el, args.workload, best, sorted(probes),
                      {k: round(v, 2) for k, v in sorted(probes.items())}),
+        'percall': {'value': round(m / el2, 3), 'unit': 'samples/s', 'cores': best,
+                    'sample': '%d iterations (%.1f s) of oracle.lss_torch.lift WITHOUT cached '
+                              'ranks (get_lidar_coor + voxel_pooling_prepare_v2 + pool per '
+                              'call: the counterpart of percall_prepare)' % (m, el2)},
     }
+
+
+def cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
 
 
 if __name__ == '__main__':

@@ -225,3 +225,33 @@ def test_intermediate_rows_match_reference_taps():
         patch, cls = g['tap_patch'][i], g['tap_cls'][i]
         assert np.linalg.norm(r[:, 1:] - patch) / np.linalg.norm(patch) < 1e-2
         assert np.linalg.norm(r[:, 0] - cls) / np.linalg.norm(cls) < 1e-2
+
+
+@pytest.mark.gpu
+def test_single_image_calls_do_not_corrupt_the_position_cache():
+    """with B == 1 the stream used to be a VIEW of the cached
+    cls + position rows, so the in-place blocks overwrote the cache and every later
+    single-image call started from garbage.  Two B == 1 calls must each equal the
+    matching half of the B == 2 call and the reference taps."""
+    g = load_golden('dinov2_tiny')
+    enc, _ = _build(g)
+    enc = enc.to('cuda:0')
+    x = torch.from_numpy(g['x']).to('cuda:0')
+    taps = [int(t) for t in g['taps']]
+    d = enc.embed_dim
+    with torch.no_grad():
+        both = [r.float().view(2, -1, d) for r in enc.intermediate_rows(x, taps)]
+        base_before = enc._pos_cache[('tok', x.shape[2], x.shape[3], x.device)][2].clone()
+        first = [r.float().view(1, -1, d) for r in enc.intermediate_rows(x[:1], taps)]
+        base_after = enc._pos_cache[('tok', x.shape[2], x.shape[3], x.device)][2]
+        assert torch.equal(base_before, base_after), 'cached position rows were overwritten'
+        second = [r.float().view(1, -1, d) for r in enc.intermediate_rows(x[1:], taps)]
+        again = [r.float().view(1, -1, d) for r in enc.intermediate_rows(x[:1], taps)]
+    for i in range(len(taps)):
+        assert torch.equal(first[i], again[i])
+        # the GEMM tiles see M = T instead of 2T rows, the arithmetic per row is the same
+        torch.testing.assert_close(first[i][0], both[i][0], rtol=0, atol=0)
+        torch.testing.assert_close(second[i][0], both[i][1], rtol=0, atol=0)
+        patch = g['tap_patch'][i]
+        got = torch.cat([first[i], second[i]])[:, 1:].cpu().numpy()
+        assert np.linalg.norm(got - patch) / np.linalg.norm(patch) < 1e-2

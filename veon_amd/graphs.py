@@ -23,8 +23,10 @@ class GraphedCallable:
     inputs into the captured (static) input tensors and replay; the returned
     tensors are the static outputs (overwritten by the next call)."""
 
-    def __init__(self, fn, example_inputs, warmup=3):
-        self.static_in = tuple(_map(t, lambda x: x.clone())
+    def __init__(self, fn, example_inputs, warmup=3, clone=True):
+        # clone=False: the example tensors THEMSELVES are the static inputs (a buffer
+        # another graph or a collective writes in place)
+        self.static_in = tuple(_map(t, lambda x: x.clone()) if clone else t
                                for t in example_inputs)
         # warm-up and capture on the SAME stream: per-stream static workspaces
         # (lss_prepare_hip.lift_workspace) and lazily built caches are then
@@ -42,6 +44,11 @@ class GraphedCallable:
     def __call__(self, *inputs):
         for dst, src in zip(self.static_in, inputs):
             _copy_into(dst, src)
+        return self.run()
+
+    def run(self):
+        """Replay on whatever the static inputs hold now (a producer -- a collective,
+        another graph -- may have written them in place)."""
         self.graph.replay()
         return self.static_out
 

@@ -79,13 +79,16 @@ class LiftWorkspace(Prepared):
     allocated ONCE (and the histogram zeroed once): a steady-state call allocates
     nothing, so a hipGraph capture of it owns no memory, and it needs no memset
     node.  The buffers are overwritten by the next call on the same stream."""
-    __slots__ = ('ws', 'ws_bytes', 'dims')
+    __slots__ = ('ws', 'ws_bytes', 'dims', 'dirty')
 
     def __init__(self, dims, vpb, device):
         B, N, D, H, W = dims
         L = _lib.lib()
         P = B * N * D * H * W
         self.dims, self.batch, self.vpb = tuple(dims), B, vpb
+        # the histogram is zero between calls (every call re-zeroes it); a call that
+        # fails part-way leaves it dirty, and the next call then takes the memset path
+        self.dirty = False
         self.ws_bytes = L.veon_lss_prepare_workspace_bytes(P, vpb * B)
         self.ws = torch.zeros(self.ws_bytes, dtype=torch.uint8, device=device)
         i32 = dict(dtype=torch.int32, device=device)
@@ -104,18 +107,35 @@ class LiftWorkspace(Prepared):
 _WORKSPACES = {}
 
 
-def lift_workspace(dims, vpb, device):
+def lift_workspace(dims, vpb, device, owner=None):
     """The LiftWorkspace of (problem size, device, current stream): two streams
-    lifting at once never share buffers."""
+    lifting at once never share buffers.  ``owner`` (a view transformer, a graphed
+    callable ...) holds its workspaces itself: they die with it and two owners never
+    share buffers, also when they capture on one stream; owner-less calls use a
+    module-level table that ``clear_workspaces()`` empties."""
     key = (tuple(dims), int(vpb), str(device),
            int(torch._C._cuda_getCurrentRawStream(
                device.index if device.index is not None else torch.cuda.current_device())))
-    ws = _WORKSPACES.get(key)
+    table = _WORKSPACES
+    if owner is not None:
+        table = owner.__dict__.setdefault('_veon_lift_workspaces', {})
+    ws = table.get(key)
     if ws is None:
         with torch.cuda.device(device):
             ws = LiftWorkspace(dims, int(vpb), device)
-        _WORKSPACES[key] = ws
+        table[key] = ws
     return ws
+
+
+def clear_workspaces(owner=None):
+    """Drop the cached workspaces (of ``owner``, or the module-level ones).  A live
+    hipGraph that captured a workspace keeps its buffers alive through torch's
+    graph pool only if they were allocated in the capture -- they are not: do not
+    clear while such a graph is still replayed."""
+    if owner is not None:
+        owner.__dict__.pop('_veon_lift_workspaces', None)
+    else:
+        _WORKSPACES.clear()
 
 
 def _grid_host(lower, interval, gsize):
@@ -179,7 +199,7 @@ def prepare_device(dims, coor, geometry, lower, interval, gsize, device):
 
 
 def prepare_cameras(frustum, sensor2ego, cam2imgs, post_rots, post_trans, bda, lower,
-                    interval, gsize, depth_weights=None, depth_eps=0.0):
+                    interval, gsize, depth_weights=None, depth_eps=0.0, owner=None):
     """The sync-free per-call prepare from the reference's camera tensors
     (get_lidar_coor's arguments) into the static LiftWorkspace: five launches, no
     allocation, no memset, no host sync.  Returns the workspace (a ``Prepared``
@@ -188,7 +208,7 @@ def prepare_cameras(frustum, sensor2ego, cam2imgs, post_rots, post_trans, bda, l
     B, N = sensor2ego.shape[:2]
     D, H, W, _ = frustum.shape
     vpb = _vpb(gsize)
-    ws = lift_workspace((B, N, D, H, W), vpb, dev)
+    ws = lift_workspace((B, N, D, H, W), vpb, dev, owner)
     xs, ys, ds = _axes(frustum, dev)
     s2e, k, pr, pt, bd = (_f32c(t) for t in (sensor2ego, cam2imgs, post_rots, post_trans,
                                               bda))
@@ -196,10 +216,12 @@ def prepare_cameras(frustum, sensor2ego, cam2imgs, post_rots, post_trans, bda, l
     args = (B, N, D, H, W, _lib.ptr(xs), _lib.ptr(ys), _lib.ptr(ds), _lib.ptr(s2e),
             _lib.ptr(k), _lib.ptr(pr), _lib.ptr(pt), _lib.ptr(bd),
             ctypes.cast(glo, ctypes.c_void_p), ctypes.cast(gstep, ctypes.c_void_p),
-            ctypes.cast(gsz, ctypes.c_void_p), vpb, _lib.ptr(ws.ws), ws.ws_bytes, 1,
+            ctypes.cast(gsz, ctypes.c_void_p), vpb, _lib.ptr(ws.ws), ws.ws_bytes,
+            0 if ws.dirty else 1,   # hist_is_zero
             _lib.ptr(ws.ranks_bev), _lib.ptr(ws.ranks_depth), _lib.ptr(ws.ranks_feat),
             _lib.ptr(ws.interval_starts), _lib.ptr(ws.interval_lengths),
             _lib.ptr(ws.plan), _lib.ptr(ws.vstart), _lib.ptr(ws.counts))
+    ws.dirty = True   # cleared below once every launch was accepted
     with _lib.on_device(dev):
         if depth_weights is not None and depth_eps > 0.0:
             # sparse lift: points whose depth weight is below depth_eps are not sorted
@@ -214,6 +236,9 @@ def prepare_cameras(frustum, sensor2ego, cam2imgs, post_rots, post_trans, bda, l
         else:
             st = _lib.lib().veon_lss_prepare_cameras(*args, _lib.stream_ptr(dev))
             _lib.check(st, 'veon_lss_prepare_cameras')
+    # a call captured into a hipGraph while the workspace was dirty has the memset in
+    # the graph; every replay then leaves a zero histogram like any other call
+    ws.dirty = False
     return ws
 
 

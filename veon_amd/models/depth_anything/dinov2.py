@@ -284,7 +284,10 @@ class DinoVisionTransformer(nn.Module):
             base[0] += self.cls_token.detach().float().view(d) - bias
             self._pos_cache[key] = (vit_ops.to_bf16(wp), bias, base.contiguous(), kpad)
         wp, bias, base, kpad = self._pos_cache[key]
-        s = base.unsqueeze(0).expand(B, -1, -1).reshape(B * base.shape[0], d)
+        # always a fresh buffer: the blocks run in place on it, and for B == 1 an
+        # expand().reshape() would be a VIEW of the cached rows
+        s = base.repeat(B, 1)
+        assert s.data_ptr() != base.data_ptr()
         a = vit_ops.patchify(x, p, 1, kpad)
         return vit_ops.linear_residual_(s, a, wp, bias)
 

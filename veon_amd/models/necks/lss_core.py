@@ -189,12 +189,13 @@ class LSSCore(_Base):
         return rows, lambda: cur.wait_stream(side)
 
     def _lift_sync_free(self, input, depth, feat):
+        self._drop_prepared()
         sensor2ego, _, cam2imgs, post_rots, post_trans, bda = input[1:7]
         feat_l, join = self._rows_beside_prepare(feat.permute(0, 1, 3, 4, 2), depth)
         pre = _prep._HIP_PREPARE.prepare_cameras(
             self.frustum, sensor2ego, cam2imgs, post_rots, post_trans, bda,
             self.grid_lower_bound, self.grid_interval, self.grid_size,
-            **self._sparse_args(depth))
+            owner=self, **self._sparse_args(depth))
         join()
         shape = self._bev_feat_shape(depth.shape[0], feat.shape[2])
         out = None
@@ -222,17 +223,25 @@ class LSSCore(_Base):
         sensor2ego, _, cam2imgs, post_rots, post_trans, bda = metas[:6]
         pre = _prep._HIP_PREPARE.prepare_cameras(
             self.frustum, sensor2ego, cam2imgs, post_rots, post_trans, bda,
-            self.grid_lower_bound, self.grid_interval, self.grid_size)
+            self.grid_lower_bound, self.grid_interval, self.grid_size, owner=self)
+        # the tensors themselves are kept (not their ids: a freed tensor's id can be
+        # reused by a new one), compared with `is` by the consumer
         self.__dict__['_prepared'] = (
-            tuple(id(t) for t in (sensor2ego, cam2imgs, post_rots, post_trans, bda)), pre)
+            (sensor2ego, cam2imgs, post_rots, post_trans, bda), pre)
         return pre
 
     def _take_prepared(self, sensor2ego, cam2imgs, post_rots, post_trans, bda):
+        """The stash of ``prepare_lift`` if it was made from exactly these tensor
+        objects; the stash is dropped either way (every lift entry point calls this
+        or ``_drop_prepared`` first, so a stale one never survives a forward)."""
         st = self.__dict__.pop('_prepared', None)
-        if st is not None and st[0] == tuple(
-                id(t) for t in (sensor2ego, cam2imgs, post_rots, post_trans, bda)):
+        if st is not None and all(a is b for a, b in zip(
+                st[0], (sensor2ego, cam2imgs, post_rots, post_trans, bda))):
             return st[1]
         return None
+
+    def _drop_prepared(self):
+        self.__dict__.pop('_prepared', None)
 
     def _lift_maxpool(self, input, depth, feat, ds, out_volume=None):
         """forward's pool + (dz,dy,dx) block max in one kernel (inference).
@@ -241,6 +250,8 @@ class LSSCore(_Base):
         B = depth.shape[0]
         shape = self._bev_feat_shape(B, feat.shape[2])
         feat = feat.permute(0, 1, 3, 4, 2)
+        if self.accelerate or not self.sync_free:
+            self._drop_prepared()
         if self.accelerate:
             self.pre_compute(input)
             return _bp.bev_pool_v2_maxpool(
@@ -255,7 +266,7 @@ class LSSCore(_Base):
                 pre = _prep._HIP_PREPARE.prepare_cameras(
                     self.frustum, sensor2ego, cam2imgs, post_rots, post_trans, bda,
                     self.grid_lower_bound, self.grid_interval, self.grid_size,
-                    **self._sparse_args(depth))
+                    owner=self, **self._sparse_args(depth))
                 join()
             return _bp.bev_pool_v2_maxpool(
                 depth, feat, pre.ranks_depth, pre.ranks_feat, pre.ranks_bev,

@@ -418,3 +418,93 @@ class VeonOccupancyPath(nn.Module):
         feats, supp, depth = self._branches(images, depth)
         out = dec(sem_embed_ds, feats, [supp], depth, metas, prev_volumes)
         return self._classify(out['bin_occ'], out['feat_occ'])
+
+
+class CameraShardedStep:
+    """``VeonOccupancyPath.forward_camera_sharded`` for a fixed shape as hipGraph
+    segments around the (eager) collectives: everything a rank computes before the
+    exchange of the voxel volume replays from one graph, everything after it from
+    another (``reduce='scatter'``: a third one for the sharded max-pool between the
+    reduce-scatter and the all-gather).  The collectives themselves stay outside the
+    graphs: they are two or three calls per step, and a captured RCCL call pins its
+    communicator and buffers into the graph for no gain.  The collectives write
+    straight into the next segment's static input, so no copy is added.
+
+    ``step(images)`` -> the output dict of the tail (static tensors, overwritten by
+    the next call).  Works without a process group (one rank, all cameras) and
+    through a 1-rank group, which is how the GPU tests exercise it."""
+
+    def __init__(self, net, images, img_metas, group=None, reduce_dtype=None,
+                 reduce='allreduce'):
+        import torch.distributed as dist
+        from .. import sharding
+        from ..graphs import GraphedCallable
+        if reduce not in ('allreduce', 'scatter'):
+            raise ValueError("reduce must be 'allreduce' or 'scatter', got %r" % (reduce,))
+        self.dist, self.group = dist, group
+        self.active = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if self.active else 1
+        rank = dist.get_rank(group) if self.active else 0
+        B, N = images.shape[:2]
+        if B != 1:
+            raise ValueError('CameraShardedStep shards the cameras of ONE sample (B = 1)')
+        lo, hi = sharding.camera_slices(N, self.world)[rank]
+        self.cameras = (lo, hi)
+        C = net.occ_decoder.layers_3d_body[0].conv1.conv.in_channels
+        self.scatter = reduce == 'scatter' and C % self.world == 0
+        rd = reduce_dtype
+
+        def pre(im):
+            vol = net.lift_cameras(im, img_metas, lo, hi)
+            return (vol if rd is None or rd == vol.dtype else vol.to(rd)).contiguous()
+
+        def mid(mine):   # own channel slice, summed over the ranks -> pooled slice
+            part = net._max_pool(mine.float())
+            return (part if rd is None else part.to(rd)).contiguous()
+
+        def post_pooled(allp):   # (world, B, C/world, z, y, x) -> (B, C, z, y, x)
+            return net.from_pooled(allp.transpose(0, 1).reshape(B, C, *allp.shape[3:]).float())
+
+        def post_volume(buf):
+            return net.from_volume(buf.float())
+
+        def wrap(f, ex):   # the example tensors themselves are the static inputs
+            return GraphedCallable(f, ex, clone=False)
+        with torch.no_grad():
+            self.pre = wrap(pre, (images.clone(),))
+            buf = self.pre.static_out
+            if self.scatter:
+                cs = C // self.world
+                mine = torch.zeros((B, cs) + tuple(buf.shape[2:]), dtype=buf.dtype,
+                                   device=buf.device)
+                self.mid = wrap(mid, (mine,))
+                part = self.mid.static_out
+                allp = torch.zeros((self.world,) + tuple(part.shape), dtype=part.dtype,
+                                   device=part.device)
+                self.post = wrap(post_pooled, (allp,))
+            else:
+                self.mid = None
+                self.post = wrap(post_volume, (buf,))
+        self.launch = '%d hipGraph segments around the eager collectives' % (
+            3 if self.scatter else 2)
+
+    def __call__(self, images):
+        dist = self.dist
+        buf = self.pre(images)
+        if self.scatter:
+            mine = self.mid.static_in[0]
+            if self.active:
+                dist.reduce_scatter_tensor(mine.view(-1), buf.view(-1),
+                                           op=dist.ReduceOp.SUM, group=self.group)
+            else:
+                mine.copy_(buf)
+            part = self.mid.run()
+            allp = self.post.static_in[0]
+            if self.active:
+                dist.all_gather_into_tensor(allp.view(-1), part.view(-1), group=self.group)
+            else:
+                allp[0].copy_(part)
+            return self.post.run()
+        if self.active:   # in place on the first segment's output = the tail's input
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+        return self.post.run()
