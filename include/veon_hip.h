@@ -343,6 +343,28 @@ int veon_lss_prepare_cameras_sparse(
     int *ranks_depth, int *ranks_feat, int *interval_starts, int *interval_lengths,
     int *plan, int *vstart, int *counts, const float *depth_weights, float depth_eps,
     void *stream);
+/*
+ * Two-hot lift by construction (view_transformer_raw.py:406-429 +
+ * 244-302 in one): the same prepare driven by veon_two_hot_window's per-pixel windows
+ * instead of a (B,N,D,H,W) weight tensor.  Point (pixel, bin k) is kept iff k lies in
+ * the pixel's kept window [q0, q0+nq), or the pixel's tail weight passed the threshold
+ * and k lies outside its unclamped window [k0, k0+nk).  ranks_depth then indexes the
+ * COMPACT weight table: pix*window_slots + (k in [k0,k0+nk) ? 1 + k - k0 : 0), so every
+ * pool entry point of this header is called with depth = wts and computes the sums of
+ * the dense lift over the kept points, in the dense lift's order (ascending point
+ * index inside a voxel).  With eps = 0 in veon_two_hot_window that is the dense lift
+ * to the bit; with eps > 0 every pooled sum moves by at most eps * sum|feat| over the
+ * dropped points of its voxel.  ranks_feat / ranks_bev / intervals / vstart / plan /
+ * counts as veon_lss_prepare_cameras.
+ */
+int veon_lss_prepare_cameras_twohot(
+    int B, int N, int D, int H, int W, const float *xs, const float *ys, const float *ds,
+    const float *sensor2ego, const float *cam2imgs, const float *post_rots,
+    const float *post_trans, const float *bda, const float *grid_lower,
+    const float *grid_interval, const float *grid_size, int64_t voxels_per_batch,
+    void *workspace, int64_t workspace_bytes, int hist_is_zero, int *ranks_bev,
+    int *ranks_depth, int *ranks_feat, int *interval_starts, int *interval_lengths,
+    int *plan, int *vstart, int *counts, const int *win, int window_slots, void *stream);
 
 int veon_lss_prepare(int B, int N, int D, int H, int W, const float *coor,
                      const float *xs, const float *ys, const float *ds,
@@ -371,6 +393,28 @@ int veon_downsample_depth(int BN, int H, int W, int ds, const float *depths,
 int veon_two_hot_depth(int BN, int H, int W, int ds, int D, float lo, float step,
                        float gamma, const float *depths, float *out,
                        void *stream);
+/*
+ * The same distribution in its compact, EXACT form (the
+ * (BN,D,H,W) tensor is never written).  A pixel's D+1 logits are -gamma*|d - c_k|
+ * where that is >= -16 and exactly -16 elsewhere (view_transformer_raw.py:419-421), so
+ * its weights take distinct values only on the contiguous window of unclamped bins
+ * [k0, k0+nk) and ONE value -- the tail exp(-16 - max)/sum -- on every other bin.
+ *   veon_two_hot_window_slots(D, step, gamma) -> K = 1 + max window length
+ *     (floor(32/(gamma*step)) + 2, capped at D); 0 on bad arguments.
+ *   wts[pix*K + 0] = tail, wts[pix*K + 1 + j] = weight of bin k0 + j (0 beyond nk);
+ *     bit-identical to veon_two_hot_depth's values of those bins.
+ *   win[2*pix]     = k0 | nk << 16            unclamped window (bins < D)
+ *   win[2*pix + 1] = q0 | nq << 16 | t << 31  [q0, q0+nq): the window bins whose
+ *     weight is >= eps (contiguous: the weights are unimodal); t = tail >= eps.
+ * depths / ds as veon_two_hot_depth (ds > 0 fuses the block-min).  pix runs over
+ * (BN, H, W).  eps = 0 keeps every bin.  win must be 8-byte aligned.
+ * Consumed by veon_lss_prepare_cameras_twohot; the pool kernels then take `wts` as
+ * their depth table.
+ */
+int veon_two_hot_window_slots(int D, float step, float gamma);
+int veon_two_hot_window(int BN, int H, int W, int ds, int D, float lo, float step,
+                        float gamma, float eps, int K, const float *depths, int *win,
+                        float *wts, void *stream);
 
 /*
  * ViT encoder block kernels (bf16 operands on MFMA, fp32 accumulate, fp32

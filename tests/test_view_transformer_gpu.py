@@ -472,7 +472,7 @@ def test_sparse_lift_drops_the_clamped_tail_within_tolerance():
 
 
 def _prep_counts(vt):
-    from veon_amd import lss_prepare_hip
-    ws = [w for k, w in lss_prepare_hip._WORKSPACES.items()
+    # the view transformer owns its lift workspaces (lss_prepare_hip.lift_workspace)
+    ws = [w for k, w in vt.__dict__['_veon_lift_workspaces'].items()
           if k[1] == int(vt.grid_size[0] * vt.grid_size[1] * vt.grid_size[2])]
     return ws[-1].counts.tolist()

@@ -34,8 +34,8 @@ def main():
     dev = 'cuda:0'
     torch.manual_seed(0)
     kw = dict(VeonOccupancyPath.VEON_L) if enc == 'vitl' else dict(encoder='vitb')
-    if '--sparse' in sys.argv:      # opt-in sparse lift
-        kw['sparse_lift_eps'] = 1e-6
+    if '--dense' in sys.argv:       # the reference's dense two-hot tensor into the lift
+        kw['sparse_lift_eps'] = None  # (default: two-hot lift by construction, eps 1e-6)
     net = VeonOccupancyPath(input_size=size, **kw).to(dev).eval()
     geom = [t.to(dev) for t in synthetic.rig_inputs(synthetic.make_rig(1, 6, size))]
     images = torch.randn(1, 6, 3, *size, device=dev)

@@ -72,6 +72,8 @@ _SIGNATURES = {
     'veon_bev_pool_v2_fwd_maxpool': (_ci, [_ci] * 9 + [_vp] * 9 + [_vp]),
     'veon_downsample_depth': (_ci, [_ci] * 4 + [_vp, _vp, _vp]),
     'veon_two_hot_depth': (_ci, [_ci] * 5 + [_cf] * 3 + [_vp, _vp, _vp]),
+    'veon_two_hot_window_slots': (_ci, [_ci, _cf, _cf]),
+    'veon_two_hot_window': (_ci, [_ci] * 5 + [_cf] * 4 + [_ci, _vp, _vp, _vp, _vp]),
     'veon_gemm_ring_set': (None, [_ci]),
     'veon_vit_cast_bf16': (_ci, [_vp, _vp, _i64, _vp]),
     'veon_vit_layernorm': (_ci, [_vp, _vp, _vp, _vp, _ci, _ci, _cf, _vp]),
@@ -112,6 +114,8 @@ _SIGNATURES = {
                                  + [_vp] * 8 + [_vp]),
     'veon_lss_prepare_cameras_sparse': (_ci, [_ci] * 5 + [_vp] * 8 + [_vp] * 3
                                         + [_i64, _vp, _i64, _ci] + [_vp] * 8 + [_vp, _cf, _vp]),
+    'veon_lss_prepare_cameras_twohot': (_ci, [_ci] * 5 + [_vp] * 8 + [_vp] * 3
+                                        + [_i64, _vp, _i64, _ci] + [_vp] * 8 + [_vp, _ci, _vp]),
     'veon_lss_prepare': (_ci, [_ci] * 5 + [_vp] * 9 + [_vp] * 3 + [_i64, _vp, _i64]
                          + [_vp] * 7 + [_vp]),
 }

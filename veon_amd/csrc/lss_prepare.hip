@@ -180,7 +180,8 @@ template <int FROM>
 __global__ __launch_bounds__(kBlock) void k_voxel_keys(
     Geometry g, CameraRaw cr, const float* __restrict__ coor, GridF gr, int N, int D,
     int H, int W, int64_t n_bins, int* __restrict__ keys, int* __restrict__ slots,
-    int* __restrict__ hist, const float* __restrict__ depth_w, float depth_eps) {
+    int* __restrict__ hist, const float* __restrict__ depth_w, float depth_eps,
+    const int2* __restrict__ win) {
   __shared__ float cam[21];  // post_rots_inv[9], combine[9], trans[3]
   const int bn = blockIdx.y;
   if constexpr (FROM == 2) {
@@ -241,6 +242,20 @@ __global__ __launch_bounds__(kBlock) void k_voxel_keys(
   // (the clamped tail of VEON's soft two-hot depth, ~1e-7 per bin) is dropped here
   // and never sorted, ranked or pooled
   if (depth_w != nullptr && key >= 0 && depth_w[p] < depth_eps) key = -1;
+  // two-hot lift by construction (csrc/depth_ops.hip k_two_hot_window): the depth
+  // weights exist only as a per-pixel window + tail; a point is kept iff its bin is in
+  // the pixel's kept window, or outside the unclamped window of a pixel whose tail
+  // weight passed the threshold
+  if (win != nullptr && key >= 0) {
+    const int hw = H * W;
+    const int k = ic / hw;
+    const int2 wv = win[(int64_t)bn * hw + (ic - k * hw)];
+    const int k0 = wv.x & 0xffff, nk = wv.x >> 16;
+    const int q0 = wv.y & 0xffff, nq = (wv.y >> 16) & 0x7fff;
+    const bool in_kept = (unsigned)(k - q0) < (unsigned)nq;
+    const bool in_tail = (wv.y < 0) && !((unsigned)(k - k0) < (unsigned)nk);
+    if (!(in_kept || in_tail)) key = -1;
+  }
   if (!valid) key = -2;
   // Neighbouring pixels of one image row mostly fall into the same voxel: a run of
   // consecutive lanes with one key takes ONE returning atomic (by its first lane,
@@ -412,7 +427,8 @@ __global__ __launch_bounds__(kBlock) void k_rank_in_bin(
     const int* __restrict__ keys, const int* __restrict__ tmp_point,
     const int* __restrict__ counts, const int* __restrict__ bin_start, int D, int HW,
     int* __restrict__ ranks_bev,
-    int* __restrict__ ranks_depth, int* __restrict__ ranks_feat) {
+    int* __restrict__ ranks_depth, int* __restrict__ ranks_feat,
+    const int2* __restrict__ win, int K) {
   __shared__ int sp[kRankSpan];
   __shared__ int lo_s, hi_s;
   const int kept = counts[0];
@@ -442,9 +458,18 @@ __global__ __launch_bounds__(kBlock) void k_rank_in_bin(
   for (int i = max(start, hi); i < end; ++i) rank += tmp_point[i] < p;
   const int slot = start + rank;
   ranks_bev[slot] = key;
-  ranks_depth[slot] = p;
   // pixel index (b,n,h,w) of point (b,n,d,h,w): view_transformer_raw.py:262-265
-  ranks_feat[slot] = (p / (D * HW)) * HW + p % HW;
+  const int pix = (p / (D * HW)) * HW + p % HW;
+  ranks_feat[slot] = pix;
+  if (win == nullptr) {
+    ranks_depth[slot] = p;
+  } else {
+    // index into the compact weight table: slot 0 = the tail, 1 + j = window bin j
+    const int k = (p / HW) % D;
+    const int wx = win[pix].x;
+    const int j = k - (wx & 0xffff);
+    ranks_depth[slot] = pix * K + ((unsigned)j < (unsigned)(wx >> 16) ? 1 + j : 0);
+  }
 }
 
 inline int launch_status() {
@@ -537,7 +562,8 @@ static int prepare_impl(int B, int N, int D, int H, int W, const float* coor,
                         int64_t workspace_bytes, int hist_is_zero, int* ranks_bev,
                         int* ranks_depth, int* ranks_feat, int* interval_starts,
                         int* interval_lengths, int* plan, int* vstart, int* counts,
-                        const float* depth_w, float depth_eps, void* stream) {
+                        const float* depth_w, float depth_eps, const int* win_i, int K,
+                        void* stream) {
   if (B <= 0 || N <= 0 || D <= 0 || H <= 0 || W <= 0 || voxels_per_batch <= 0)
     return VEON_ERR_BAD_ARG;
   if (!grid_lower || !grid_interval || !grid_size || !workspace || !ranks_bev ||
@@ -559,6 +585,10 @@ static int prepare_impl(int B, int N, int D, int H, int W, const float* coor,
   if (plan && (reinterpret_cast<uintptr_t>(plan) & 15u)) return VEON_ERR_BAD_ARG;
   const Workspace w = carve(workspace, P, n_bins);
   if (w.bytes > workspace_bytes) return VEON_ERR_WORKSPACE;
+  const int2* win = reinterpret_cast<const int2*>(win_i);
+  if (win && (K <= 0 || coor || (reinterpret_cast<uintptr_t>(win) & 7u) ||
+              (int64_t)B * N * H * W * K > 0x7fffffffLL))
+    return VEON_ERR_BAD_ARG;
   hipStream_t s = static_cast<hipStream_t>(stream);
   GridF gr;
   for (int i = 0; i < 3; ++i) {
@@ -578,13 +608,13 @@ static int prepare_impl(int B, int N, int D, int H, int W, const float* coor,
   const dim3 kgrid((unsigned)((dhw + kBlock - 1) / kBlock), (unsigned)(B * N));
   if (coor)
     hipLaunchKernelGGL(k_voxel_keys<1>, kgrid, dim3(kBlock), 0, s, g, cr, coor, gr, N,
-                       D, H, W, n_bins, w.keys, w.slots, w.hist, depth_w, depth_eps);
+                       D, H, W, n_bins, w.keys, w.slots, w.hist, depth_w, depth_eps, win);
   else if (raw)
     hipLaunchKernelGGL(k_voxel_keys<2>, kgrid, dim3(kBlock), 0, s, g, cr, coor, gr, N,
-                       D, H, W, n_bins, w.keys, w.slots, w.hist, depth_w, depth_eps);
+                       D, H, W, n_bins, w.keys, w.slots, w.hist, depth_w, depth_eps, win);
   else
     hipLaunchKernelGGL(k_voxel_keys<0>, kgrid, dim3(kBlock), 0, s, g, cr, coor, gr, N,
-                       D, H, W, n_bins, w.keys, w.slots, w.hist, depth_w, depth_eps);
+                       D, H, W, n_bins, w.keys, w.slots, w.hist, depth_w, depth_eps, win);
   const int64_t tiles_per_batch = voxels_per_batch / kTileV;
   hipLaunchKernelGGL(k_scan_reduce, dim3(n_scan_blocks), dim3(kBlock), 0, s,
                      w.hist, n_bins, w.block_sums);
@@ -596,7 +626,7 @@ static int prepare_impl(int B, int N, int D, int H, int W, const float* coor,
                      table, w.tmp_point);
   hipLaunchKernelGGL(k_rank_in_bin, dim3(pb), dim3(kBlock), 0, s, w.keys,
                      w.tmp_point, counts, table, D, H * W, ranks_bev, ranks_depth,
-                     ranks_feat);
+                     ranks_feat, win, K);
   return launch_status();
 }
 
@@ -615,7 +645,7 @@ int veon_lss_prepare(int B, int N, int D, int H, int W, const float* coor,
                       grid_interval, grid_size, voxels_per_batch, workspace,
                       workspace_bytes, 0, ranks_bev, ranks_depth, ranks_feat,
                       interval_starts, interval_lengths, plan, nullptr, counts, nullptr,
-                      0.f, stream);
+                      0.f, nullptr, 0, stream);
 }
 
 int veon_lss_prepare_cameras(int B, int N, int D, int H, int W, const float* xs,
@@ -635,7 +665,7 @@ int veon_lss_prepare_cameras(int B, int N, int D, int H, int W, const float* xs,
                       grid_interval, grid_size, voxels_per_batch, workspace,
                       workspace_bytes, hist_is_zero, ranks_bev, ranks_depth,
                       ranks_feat, interval_starts, interval_lengths, plan, vstart,
-                      counts, nullptr, 0.f, stream);
+                      counts, nullptr, 0.f, nullptr, 0, stream);
 }
 
 int veon_lss_prepare_cameras_sparse(
@@ -653,7 +683,24 @@ int veon_lss_prepare_cameras_sparse(
                       grid_interval, grid_size, voxels_per_batch, workspace,
                       workspace_bytes, hist_is_zero, ranks_bev, ranks_depth,
                       ranks_feat, interval_starts, interval_lengths, plan, vstart,
-                      counts, depth_weights, depth_eps, stream);
+                      counts, depth_weights, depth_eps, nullptr, 0, stream);
+}
+
+int veon_lss_prepare_cameras_twohot(
+    int B, int N, int D, int H, int W, const float* xs, const float* ys, const float* ds,
+    const float* sensor2ego, const float* cam2imgs, const float* post_rots,
+    const float* post_trans, const float* bda, const float* grid_lower,
+    const float* grid_interval, const float* grid_size, int64_t voxels_per_batch,
+    void* workspace, int64_t workspace_bytes, int hist_is_zero, int* ranks_bev,
+    int* ranks_depth, int* ranks_feat, int* interval_starts, int* interval_lengths,
+    int* plan, int* vstart, int* counts, const int* win, int window_slots, void* stream) {
+  if (!sensor2ego || !win || window_slots <= 0) return VEON_ERR_BAD_ARG;
+  return prepare_impl(B, N, D, H, W, nullptr, xs, ys, ds, nullptr, post_trans, nullptr,
+                      nullptr, bda, sensor2ego, cam2imgs, post_rots, grid_lower,
+                      grid_interval, grid_size, voxels_per_batch, workspace,
+                      workspace_bytes, hist_is_zero, ranks_bev, ranks_depth,
+                      ranks_feat, interval_starts, interval_lengths, plan, vstart,
+                      counts, nullptr, 0.f, win, window_slots, stream);
 }
 
 }  // extern "C"

@@ -199,7 +199,8 @@ def prepare_device(dims, coor, geometry, lower, interval, gsize, device):
 
 
 def prepare_cameras(frustum, sensor2ego, cam2imgs, post_rots, post_trans, bda, lower,
-                    interval, gsize, depth_weights=None, depth_eps=0.0, owner=None):
+                    interval, gsize, depth_weights=None, depth_eps=0.0, owner=None,
+                    twohot=None):
     """The sync-free per-call prepare from the reference's camera tensors
     (get_lidar_coor's arguments) into the static LiftWorkspace: five launches, no
     allocation, no memset, no host sync.  Returns the workspace (a ``Prepared``
@@ -223,7 +224,19 @@ def prepare_cameras(frustum, sensor2ego, cam2imgs, post_rots, post_trans, bda, l
             _lib.ptr(ws.plan), _lib.ptr(ws.vstart), _lib.ptr(ws.counts))
     ws.dirty = True   # cleared below once every launch was accepted
     with _lib.on_device(dev):
-        if depth_weights is not None and depth_eps > 0.0:
+        if twohot is not None:
+            # two-hot lift by construction: ``twohot`` = depth_ops.TwoHotWindows; the
+            # returned ranks_depth index its compact weight table ``twohot.wts``
+            if (tuple(twohot.shape) != (B, N, D, H, W) or twohot.device != dev
+                    or twohot.win.dtype != torch.int32 or not twohot.win.is_contiguous()
+                    or not twohot.wts.is_contiguous()):
+                raise _lib.VeonHipError(
+                    'two-hot windows of shape %r on %s do not match the frustum %r on %s'
+                    % (tuple(twohot.shape), twohot.device, (B, N, D, H, W), dev))
+            st = _lib.lib().veon_lss_prepare_cameras_twohot(
+                *args, _lib.ptr(twohot.win), int(twohot.K), _lib.stream_ptr(dev))
+            _lib.check(st, 'veon_lss_prepare_cameras_twohot')
+        elif depth_weights is not None and depth_eps > 0.0:
             # sparse lift: points whose depth weight is below depth_eps are not sorted
             if (depth_weights.dtype != torch.float32 or not depth_weights.is_contiguous()
                     or depth_weights.numel() != B * N * D * H * W

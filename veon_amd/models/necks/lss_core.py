@@ -159,6 +159,16 @@ class LSSCore(_Base):
             bev_feat = torch.cat(bev_feat.unbind(dim=2), 1)
         return bev_feat
 
+    def _depth_table(self, depth):
+        """-> (the float table the pool kernels index with ``ranks_depth``, extra
+        arguments of the prepare).  A dense (B,N,D,H,W) tensor is its own table; a
+        ``depth_ops.TwoHotWindows`` (the two-hot lift by construction) hands its
+        compact weight table to the pool and its windows to the prepare."""
+        from ... import depth_ops
+        if isinstance(depth, depth_ops.TwoHotWindows):
+            return depth.wts, dict(twohot=depth)
+        return depth, self._sparse_args(depth)
+
     def _sparse_args(self, depth):
         """``sparse_depth_eps`` (opt-in, default None = every frustum point, the
         reference's sums to the bit): in the sync-free lift, points whose depth
@@ -191,11 +201,12 @@ class LSSCore(_Base):
     def _lift_sync_free(self, input, depth, feat):
         self._drop_prepared()
         sensor2ego, _, cam2imgs, post_rots, post_trans, bda = input[1:7]
+        depth, extra = self._depth_table(depth)
         feat_l, join = self._rows_beside_prepare(feat.permute(0, 1, 3, 4, 2), depth)
         pre = _prep._HIP_PREPARE.prepare_cameras(
             self.frustum, sensor2ego, cam2imgs, post_rots, post_trans, bda,
             self.grid_lower_bound, self.grid_interval, self.grid_size,
-            owner=self, **self._sparse_args(depth))
+            owner=self, **extra)
         join()
         shape = self._bev_feat_shape(depth.shape[0], feat.shape[2])
         out = None
@@ -260,13 +271,17 @@ class LSSCore(_Base):
                 out_volume=out_volume)
         sensor2ego, _, cam2imgs, post_rots, post_trans, bda = input[1:7]
         if self.sync_free:
-            pre = self._take_prepared(sensor2ego, cam2imgs, post_rots, post_trans, bda)
+            depth, extra = self._depth_table(depth)
+            pre = None if extra else self._take_prepared(sensor2ego, cam2imgs, post_rots,
+                                                         post_trans, bda)
+            if extra:
+                self._drop_prepared()
             if pre is None:
                 feat, join = self._rows_beside_prepare(feat, depth)
                 pre = _prep._HIP_PREPARE.prepare_cameras(
                     self.frustum, sensor2ego, cam2imgs, post_rots, post_trans, bda,
                     self.grid_lower_bound, self.grid_interval, self.grid_size,
-                    owner=self, **self._sparse_args(depth))
+                    owner=self, **extra)
                 join()
             return _bp.bev_pool_v2_maxpool(
                 depth, feat, pre.ranks_depth, pre.ranks_feat, pre.ranks_bev,
@@ -306,8 +321,10 @@ class LSSCore(_Base):
             bev_feat = bev_feat.squeeze(2)
         elif (self.sync_free and tran_feat.is_cuda
               and not torch.is_grad_enabled()):
+            from ... import depth_ops
             bev_feat = self._lift_sync_free(
-                input, depth.view(B, N, self.D, H, W),
+                input, depth if isinstance(depth, depth_ops.TwoHotWindows)
+                else depth.view(B, N, self.D, H, W),
                 tran_feat.view(B, N, self.out_channels, H, W))
         else:
             coor = self.get_lidar_coor(*input[1:7])

@@ -69,9 +69,21 @@ class AlignNetOcc3D(nn.Module):
         return super()._apply(fn, *args, **kwargs)
 
     # ------------------------------------------------------------ preparation
+    # veon_amd extension: None = the reference's dense (B,N,D,Hf,Wf)
+    # two-hot tensor; a float eps >= 0 = the two-hot lift by construction -- at
+    # inference on a ROCm device ``prepare_depth`` returns ``depth_ops.TwoHotWindows``
+    # (compact exact weights; points with weight < eps dropped before the sort; 0 =
+    # the dense lift to the bit) and the D-wide tensor is never written.
+    two_hot_eps = None
+
     def prepare_depth(self, depth):
-        depth_ds = self.lss_view_transformer.downsample_depth(depth, downsample=8)
-        return self.lss_view_transformer.get_two_hot_depth(depth_ds)
+        vt = self.lss_view_transformer
+        if (self.two_hot_eps is not None and depth.is_cuda and not torch.is_grad_enabled()
+                and getattr(vt, 'sync_free', False) and not vt.accelerate
+                and hasattr(vt, 'get_two_hot_windows')):
+            return vt.get_two_hot_windows(depth, downsample=8, eps=float(self.two_hot_eps))
+        depth_ds = vt.downsample_depth(depth, downsample=8)
+        return vt.get_two_hot_depth(depth_ds)
 
     def prepare_meta(self, img_metas):
         N = self.num_camera

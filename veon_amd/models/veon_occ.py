@@ -55,7 +55,7 @@ class VeonOccupancyPath(nn.Module):
                  occ_size=(16, 200, 200), bf16_heads=True, two_streams=True,
                  hsa_dim=384, hsa_fusion_map=('0->3->3', '1->6->6', '2->9->9'),
                  num_temporal=1, clip_patch=16, clip_image=224, side_adapter=None,
-                 sparse_lift_eps=None):
+                 sparse_lift_eps=1e-6):
         super().__init__()
         from .. import synthetic
         grid_config = grid_config or synthetic.GRID_VEON
@@ -93,14 +93,19 @@ class VeonOccupancyPath(nn.Module):
             type='LSSViewTransformerRaw', grid_config=grid_config, input_size=input_size,
             out_channels=embed_dim, collapse_z=False, ds_feat=[2, 2, 2]))
         self.view_transformer.sync_free = True
-        # opt-in: drop frustum points whose two-hot depth weight is below this before
-        # the sort (lss_core._sparse_args); None = the reference's sums to the bit
-        self.view_transformer.sparse_depth_eps = sparse_lift_eps
+        # the two-hot lift by construction (default): the depth map
+        # goes into the lift as per-pixel windows of the two-hot distribution
+        # (depth_ops.TwoHotWindows), the (B,6,D,Hf,Wf) tensor is never written, and
+        # frustum points whose weight is below ``sparse_lift_eps`` are dropped before
+        # the sort (pooled sums move by <= eps * sum|feat| of the dropped points; 0.0 =
+        # the dense lift to the bit).  None = the reference's dense two-hot tensor.
+        self.view_transformer.sparse_depth_eps = None
         self.occ_decoder = AlignNetOcc3D(
             clip_dim=clip_width, hsa_dim=hsa_dim, embed_dim=embed_dim,
             clip_outdim=clip_proj_dim, layer_lifting_map=['%d->0->0' % clip_layers],
             fusion_type='cat_fusion', layer_depth=4, num_temporal=num_temporal)
         self.occ_decoder.lss_view_transformer = self.view_transformer
+        self.occ_decoder.two_hot_eps = sparse_lift_eps
         self.occ_decoder.num_frame, self.occ_decoder.num_camera = 1, num_cam
         self.ov_classifier_weight = nn.Parameter(torch.randn(n_classes, clip_proj_dim))
         self.input_size, self.num_cam, self.occ_size = input_size, num_cam, occ_size
@@ -172,7 +177,8 @@ class VeonOccupancyPath(nn.Module):
             if metas is None:
                 return None
             m2 = dec.prepare_meta(metas)
-            self.view_transformer.prepare_lift(m2)
+            if dec.two_hot_eps is None:   # (the two-hot lift's prepare needs the depth)
+                self.view_transformer.prepare_lift(m2)
             return m2
 
         def sem():   # CLIP -> HSA -> CLIP tail, then (fast path) the 2-D fusion layer
@@ -287,8 +293,10 @@ class VeonOccupancyPath(nn.Module):
         fused = dec.fusion_layers['layer_0']([supp][src_ec], feats[src_clip], (hf, wf))
         feats_2d = fused.reshape(B, n, fused.shape[1], hf, wf)
         local = [t[:, lo:hi].contiguous() for t in metas[:5]] + [metas[5]]
+        from .. import depth_ops
         vol = vt.view_transform([feats_2d] + local,
-                                depth2.reshape(B * n, -1, hf, wf),
+                                depth2 if isinstance(depth2, depth_ops.TwoHotWindows)
+                                else depth2.reshape(B * n, -1, hf, wf),
                                 feats_2d.reshape(B * n, -1, hf, wf).float())
         return vol if vol.dim() == 5 else vol.view(B, C, z, y, x)
 
