@@ -206,6 +206,41 @@ int veon_bev_pool_v2_fwd_rows_maxpool(int c, int batch, int Z, int Y, int X, int
                                       const int *ranks_depth, const int *ranks_feat,
                                       const int *vstart, void *out, int out_padded_bf16,
                                       int64_t feat_elems, void *stream);
+/*
+ * The same with a caller-given order of the short-list ("cold") work: the pooled
+ * volume is cut into chunks of veon_bev_pool_rows_maxpool_chunk() consecutive pooled
+ * voxels per batch element (linear (zo, yo, xo) order, chunk id = b * chunks_per_batch
+ * + index), cold workgroup i processes chunk chunk_order[i]; chunk_order must be a
+ * permutation of all B * ceil(plane / chunk) chunk ids (NULL = built-in order).  Pure
+ * scheduling: results never depend on it.  Workgroups are dealt to the eight XCDs
+ * round-robin, so an order that gives every XCD the chunks of one azimuth sector around
+ * the rig keeps the feature rows of that sector's cameras in the XCD's own 4 MiB L2
+ * (veon_amd/ops/bev_pool_v2/bev_pool.py `cold_chunk_order`).
+ */
+int veon_bev_pool_rows_maxpool_chunk(void);
+/* part: 0 = the whole job in one launch; 1 = only the short lists (the "cold"
+ * workgroups), 2 = only the long lists (the "workers").  Parts 1 and 2 write disjoint
+ * pooled voxels and together equal part 0: a caller launches them on TWO streams so
+ * that they run side by side (the workers' deep row pipelines need registers that
+ * would halve the occupancy of the short-list path inside one kernel). */
+int veon_bev_pool_v2_fwd_rows_maxpool_part(
+    int c, int batch, int Z, int Y, int X, int dz, int dy, int dx, const float *depth,
+    const void *feat, int feat_dtype, const int *ranks_depth, const int *ranks_feat,
+    const int *vstart, void *out, int out_padded_bf16, int64_t feat_elems,
+    const int *chunk_order, int part, void *stream);
+/* tools/mp_prof.py: with debug bit 20 set, the worker workgroups of the row max-pool
+ * kernel leave 8 uint64 each (100 MHz stamps: entry, after the scan, exit; counts:
+ * lists, short chains, long chains; wave 0's time in the short-chain phase); this
+ * copies them to host memory (synchronises). */
+int veon_pool_prof_read(void *dst_host, int64_t bytes);
+/* 4 uint64 per segment (first 256 of worker (debug flags >> 21)): segment start, loads
+ * issued, token acquired, done (100 MHz) */
+int veon_pool_prof_read2(void *dst_host, int64_t bytes);
+int veon_bev_pool_v2_fwd_rows_maxpool_ordered(
+    int c, int batch, int Z, int Y, int X, int dz, int dy, int dx, const float *depth,
+    const void *feat, int feat_dtype, const int *ranks_depth, const int *ranks_feat,
+    const int *vstart, void *out, int out_padded_bf16, int64_t feat_elems,
+    const int *chunk_order, void *stream);
 
 /*
  * Half-precision feature rows.  QuickCumsumCuda.forward widens feat to fp32

@@ -66,6 +66,13 @@ _SIGNATURES = {
                                         _i64, _i64, _ci, _vp]),
     'veon_bev_pool_v2_fwd_rows_maxpool': (_ci, [_ci] * 8 + [_vp, _vp, _ci, _vp, _vp, _vp, _vp,
                                                 _ci, _i64, _vp]),
+    'veon_bev_pool_rows_maxpool_chunk': (_ci, []),
+    'veon_pool_prof_read': (_ci, [_vp, _i64]),
+    'veon_pool_prof_read2': (_ci, [_vp, _i64]),
+    'veon_bev_pool_v2_fwd_rows_maxpool_ordered': (_ci, [_ci] * 8 + [_vp, _vp, _ci, _vp, _vp, _vp,
+                                                        _vp, _ci, _i64, _vp, _vp]),
+    'veon_bev_pool_v2_fwd_rows_maxpool_part': (_ci, [_ci] * 8 + [_vp, _vp, _ci, _vp, _vp, _vp,
+                                                     _vp, _ci, _i64, _vp, _ci, _vp]),
     'veon_bev_pool_plan_ints': (_i64, [_ci, _i64]),
     'veon_bev_pool_plan': (_ci, [_ci, _ci, _ci, _i64, _vp, _vp, _vp, _vp, _vp]),
     'veon_bev_pool_row_table': (_ci, [_ci, _ci, _ci, _i64, _ci, _vp, _vp, _vp, _vp, _vp, _vp]),

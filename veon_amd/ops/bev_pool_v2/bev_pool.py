@@ -16,6 +16,8 @@ voxel_pooling_prepare_v2 always produces; for hand-made inputs that are not
 sorted the op falls back to the reference's three-pass structure (still HIP).
 There is no CPU path.
 """
+import os
+
 import torch
 
 from ... import _lib
@@ -237,10 +239,74 @@ def rows_forward(depth, feat, ranks_depth, ranks_feat, vstart, bev_feat_shape,
     return out
 
 
+_COLD_ORDERS = {}
+COLD_ORDER = os.environ.get('VEON_COLD_ORDER', 'azimuth')   # tools: 'none' = built-in order
+
+
+def cold_chunk_order(B, Zo, Yo, Xo, device, sectors=4, origin=None):
+    """Order of the short-list chunks of the row max-pool kernel (include/veon_hip.h
+    ``veon_bev_pool_v2_fwd_rows_maxpool_ordered``): chunks of the pooled volume sorted
+    by AZIMUTH of their centre around ``origin`` (pooled-voxel coordinates (x, y);
+    default: the centre of the grid, where the rig sits for every config of the
+    reference) and dealt so that the workgroups one XCD receives (round-robin by
+    linear id: i % 8) walk through ``sectors`` contiguous azimuth wedges.  A camera
+    ray stays inside its wedge, so an XCD's 4 MiB L2 sees the feature rows of the one
+    or two cameras that look that way (1/8 of the table) instead of all of them.  A
+    static function of the grid: computed once on the host, cached on the device."""
+    key = (int(B), int(Zo), int(Yo), int(Xo), str(device), int(sectors),
+           None if origin is None else (float(origin[0]), float(origin[1])))
+    tab = _COLD_ORDERS.get(key)
+    if tab is None:
+        import numpy as np
+        chunk = _lib.lib().veon_bev_pool_rows_maxpool_chunk()
+        plane = Zo * Yo * Xo
+        nch = (plane + chunk - 1) // chunk
+        ctr = np.minimum(np.arange(nch) * chunk + chunk // 2, plane - 1)
+        xo, yo, zo = ctr % Xo, (ctr // Xo) % Yo, ctr // (Xo * Yo)
+        ox, oy = (Xo / 2.0, Yo / 2.0) if origin is None else origin
+        az = np.arctan2(yo + 0.5 - oy, xo + 0.5 - ox)
+        rad = np.hypot(yo + 0.5 - oy, xo + 0.5 - ox)
+        srt = np.lexsort((rad, zo, az))                  # azimuth, then z, then radius
+        # 8 * sectors equal pieces of the sorted list; XCD k takes pieces k, k + 8, ...
+        pieces = np.array_split(srt, 8 * sectors)
+        per_xcd = [np.concatenate([pieces[k + 8 * j] for j in range(sectors)])
+                   for k in range(8)]
+        # cold workgroup i runs on XCD i % 8 and is that XCD's (i // 8)-th: deal the
+        # XCDs' lists round-robin; lists differ in length by at most `sectors` chunks,
+        # the leftovers go to whatever slots remain (still a permutation)
+        order = np.full(nch, -1, dtype=np.int64)
+        left = []
+        for k, lst in enumerate(per_xcd):
+            slots = np.arange(k, nch, 8)
+            n = min(len(slots), len(lst))
+            order[slots[:n]] = lst[:n]
+            left.extend(lst[n:].tolist())
+        order[order < 0] = np.array(left, dtype=np.int64)
+        assert np.array_equal(np.sort(order), np.arange(nch))
+        full = np.concatenate([order + b * nch for b in range(B)]).astype(np.int32)
+        tab = torch.from_numpy(full).to(device)
+        _COLD_ORDERS[key] = tab
+    return tab
+
+
+_SIDE_STREAMS = {}
+SPLIT_LAUNCH = os.environ.get('VEON_POOL_SPLIT', '1') != '0'
+
+
+def _side_stream(dev):
+    s = _SIDE_STREAMS.get(dev)
+    if s is None:
+        s = _SIDE_STREAMS[dev] = torch.cuda.Stream(dev)
+    return s
+
+
 def rows_maxpool(depth, feat, ranks_depth, ranks_feat, vstart, bev_feat_shape, ds,
-                 out_volume=None):
+                 out_volume=None, chunk_order='default', split=None):
     """Pool + (2,2,2) block max by the row kernel: (B,C,Z/2,Y/2,X/2) fp32, or the
-    Conv3d body's padded bf16 input when ``out_volume`` is given."""
+    Conv3d body's padded bf16 input when ``out_volume`` is given.  ``chunk_order``:
+    an int32 permutation of the cold chunks, None for the kernel's built-in order,
+    'default' = ``cold_chunk_order`` (azimuth sectors per XCD).  ``split`` (default
+    on): the long lists and the short lists as two launches on two streams."""
     B, Z, Y, X, C = [int(s) for s in bev_feat_shape]
     dz, dy, dx = [int(v) for v in ds]
     dev = _lib.require_device(depth, feat, ranks_depth, ranks_feat, vstart)
@@ -255,13 +321,34 @@ def rows_maxpool(depth, feat, ranks_depth, ranks_feat, vstart, bev_feat_shape, d
         ret = torch.empty((B, C, Z // dz, Y // dy, X // dx), dtype=torch.float32,
                           device=dev)
         target, padded = ret, 0
-    with _lib.on_device(dev):
-        st = _lib.lib().veon_bev_pool_v2_fwd_rows_maxpool(
-            C, B, Z, Y, X, dz, dy, dx, _lib.ptr(depth), _lib.ptr(feat),
-            _feat_code(feat), _lib.ptr(ranks_depth), _lib.ptr(ranks_feat),
-            _lib.ptr(vstart), _lib.ptr(target), padded, feat.numel(),
-            _lib.stream_ptr(dev))
-    _lib.check(st, 'veon_bev_pool_v2_fwd_rows_maxpool')
+    if isinstance(chunk_order, str):
+        chunk_order = (cold_chunk_order(B, Z // dz, Y // dy, X // dx, dev)
+                       if COLD_ORDER == 'azimuth' else None)
+    if chunk_order is not None:
+        chunk = _lib.lib().veon_bev_pool_rows_maxpool_chunk()
+        want = B * (((Z // dz) * (Y // dy) * (X // dx) + chunk - 1) // chunk)
+        if (chunk_order.dtype != torch.int32 or chunk_order.numel() != want
+                or chunk_order.device != dev or not chunk_order.is_contiguous()):
+            raise _lib.VeonHipError('chunk_order must be a contiguous int32 permutation '
+                                    'of %d chunks on %s' % (want, dev))
+    def launch(part):
+        with _lib.on_device(dev):
+            st = _lib.lib().veon_bev_pool_v2_fwd_rows_maxpool_part(
+                C, B, Z, Y, X, dz, dy, dx, _lib.ptr(depth), _lib.ptr(feat),
+                _feat_code(feat), _lib.ptr(ranks_depth), _lib.ptr(ranks_feat),
+                _lib.ptr(vstart), _lib.ptr(target), padded, feat.numel(),
+                _lib.ptr(chunk_order), part, _lib.stream_ptr(dev))
+        _lib.check(st, 'veon_bev_pool_v2_fwd_rows_maxpool_part')
+    if SPLIT_LAUNCH if split is None else split:
+        # long lists on a forked stream beside the short-list launch (disjoint outputs)
+        cur, side = torch.cuda.current_stream(dev), _side_stream(dev)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            launch(2)
+        launch(1)
+        cur.wait_stream(side)
+    else:
+        launch(0)
     return ret
 
 
