@@ -405,7 +405,8 @@ def veon_path(args, dev, encoder, size, steps, warmup, dist, world):
 VEON_WHAT = ('the 3-D occupancy path of VeonTemporal.simple_test '
              '(veon_amd/models/veon_occ.py): DA-V2 %s + DPT head -> depth; CLIP %s first '
              'blocks -> HSA network -> CLIP tail with attention biases; CatFusionLift -> '
-             'sync-free lift (D=88, C=256, 200x200x16, fused 2x2x2 max-pool) -> 4x '
+             'two-hot lift by construction (depth map -> per-pixel windows, eps 1e-6; D=88, '
+             'C=256, 200x200x16, sync-free prepare, fused 2x2x2 max-pool) -> 4x '
              'ResBlock3D -> occ/sem heads -> open-vocab classifier -> upsample -> arg-max; '
              '%s operands on MFMA (fp32 accumulation), random weights; timm side-adapter ViT '
              '/ mask decoder / text encoder not included')
@@ -831,6 +832,46 @@ def main():
                         'higher, throughput is what is reported'}
         except Exception as e:  # report, do not hide
             print('veonb sub-object failed: %r' % (e,), file=sys.stderr)
+    if solo and not args.no_veonb and args.workload == 'S2':
+        # the same forward WITH the 2-D mask branch the reference always runs beside it
+        # (SAN side-adapter ViT on the full-resolution image -> mask proposals ->
+        # attention biases -> CLIP recognition head -> class logits -> 2-D semantic
+        # maps; san_in_veon_temporal.py:123-139, 176-186): SURVEY 8 row f3
+        try:
+            from veon_amd import synthetic as syn
+            from veon_amd.graphs import GraphedCallable
+            from veon_amd.models.veon_occ import VeonOccupancyPath
+            torch.cuda.empty_cache()
+            torch.manual_seed(0)
+            net2 = VeonOccupancyPath(input_size=(256, 704), encoder='vitb',
+                                     side_adapter=True).to(dev).eval()
+            geom2 = [t.to(dev) for t in syn.rig_inputs(syn.make_rig(1, 6, (256, 704)))]
+            im2 = torch.randn(1, 6, 3, 256, 704, device=dev)
+            with torch.no_grad():
+                launch2 = 'one hipGraph of the whole forward'
+                try:
+                    g2d = GraphedCallable(lambda im: net2(im, geom2, with_2d=True), (im2,))
+                    step2d = g2d.graph.replay
+                except Exception as e:  # report, do not hide
+                    print('with-2d capture failed (%r); eager' % (e,), file=sys.stderr)
+                    launch2 = 'eager'
+                    step2d = lambda: net2(im2, geom2, with_2d=True)  # noqa: E731
+                g3d = GraphedCallable(lambda im: net2(im, geom2), (im2,))
+                ms2d = timed_steps(step2d, 20, 3, None, dev) / 20 * 1e3
+                ms3d = timed_steps(g3d.graph.replay, 20, 3, None, dev) / 20 * 1e3
+            result['veonb_with_2d'] = {
+                'what': 'VEONB forward + the 2-D open-vocabulary mask branch on the same CLIP '
+                        'features: side-adapter ViT (width 240, 6 heads of 40, 8 blocks, 100 '
+                        'queries; blocks on the MFMA kernels, width padded to 256 / heads to '
+                        '64) + mask decoder + recognition head + 2-D semantic inference',
+                'ms_per_step': round(ms2d, 4), 'samples_per_s': round(1e3 / ms2d, 2),
+                'ms_per_step_3d_only_same_instance': round(ms3d, 4),
+                'branch_2d_ms': round(ms2d - ms3d, 4), 'steps': 20, 'dtype': 'bf16',
+                'launch': launch2}
+            del net2, g3d
+            torch.cuda.empty_cache()
+        except Exception as e:  # report, do not hide
+            print('veonb_with_2d sub-object failed: %r' % (e,), file=sys.stderr)
     if solo and not args.no_veonl and args.workload == 'S2':
         # BASELINE configs[4] on one GPU: VEON-L, fp16 operands, hipGraph-captured
         # forward (8 x data-parallel = 8 such replicas, no collective)

@@ -218,24 +218,6 @@ int veon_bev_pool_v2_fwd_rows_maxpool(int c, int batch, int Z, int Y, int X, int
  * (veon_amd/ops/bev_pool_v2/bev_pool.py `cold_chunk_order`).
  */
 int veon_bev_pool_rows_maxpool_chunk(void);
-/* part: 0 = the whole job in one launch; 1 = only the short lists (the "cold"
- * workgroups), 2 = only the long lists (the "workers").  Parts 1 and 2 write disjoint
- * pooled voxels and together equal part 0: a caller launches them on TWO streams so
- * that they run side by side (the workers' deep row pipelines need registers that
- * would halve the occupancy of the short-list path inside one kernel). */
-int veon_bev_pool_v2_fwd_rows_maxpool_part(
-    int c, int batch, int Z, int Y, int X, int dz, int dy, int dx, const float *depth,
-    const void *feat, int feat_dtype, const int *ranks_depth, const int *ranks_feat,
-    const int *vstart, void *out, int out_padded_bf16, int64_t feat_elems,
-    const int *chunk_order, int part, void *stream);
-/* tools/mp_prof.py: with debug bit 20 set, the worker workgroups of the row max-pool
- * kernel leave 8 uint64 each (100 MHz stamps: entry, after the scan, exit; counts:
- * lists, short chains, long chains; wave 0's time in the short-chain phase); this
- * copies them to host memory (synchronises). */
-int veon_pool_prof_read(void *dst_host, int64_t bytes);
-/* 4 uint64 per segment (first 256 of worker (debug flags >> 21)): segment start, loads
- * issued, token acquired, done (100 MHz) */
-int veon_pool_prof_read2(void *dst_host, int64_t bytes);
 int veon_bev_pool_v2_fwd_rows_maxpool_ordered(
     int c, int batch, int Z, int Y, int X, int dz, int dy, int dx, const float *depth,
     const void *feat, int feat_dtype, const int *ranks_depth, const int *ranks_feat,
@@ -547,6 +529,19 @@ int veon_vit_block(float *x, const veon_vit_block_weights *w,
                    int64_t bias_head_stride, void *workspace,
                    int64_t workspace_bytes, int B, int T, int d, int H,
                    void *stream);
+/*
+ * LayerNorm of PADDED rows: x fp32 [T, ld], the token is the first d columns (the rest
+ * is padding up to the multiples of 64 the GEMM kernels need); statistics over d,
+ * out bf16 [T, ld] with zeros in the padding.  For transformer widths that are not a
+ * multiple of 64 -- SAN's side-adapter ViT, width 240 / head_dim 40
+ * (side_adaptor_in_veon.py:194-241, timm_wrapper.py:67-74): its blocks run on the
+ * kernels above with the width padded to 256 and every head to 64 (zero weight rows /
+ * columns, q scaled by 40^-0.5 as before).
+ */
+int veon_vit_layernorm_padded(const float *x, const float *gamma, const float *beta,
+                              void *out_bf16, int T, int d, int ld, float eps,
+                              void *stream);
+
 
 /*
  * ---- 3x3x3 Conv3d body of the 3D alignment network ----

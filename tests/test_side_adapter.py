@@ -120,9 +120,63 @@ def test_path_exposes_the_2d_branch():
 
 
 @pytest.mark.gpu
+def test_side_adapter_blocks_on_the_mfma_kernels():
+    """the side-adapter ViT on the HIP kernels (width 48 -> 64, head_dim
+    16 -> 64 by zero padding, LayerNorm over the real columns) against the reference
+    vector of tests/golden/side_adapter_tiny.npz (the reference's own classes around a
+    restated timm block: UNPINNED block, pinned wiring) and against the fp32 PyTorch
+    path on the same weights.  Tolerance: bf16 operands with fp32 accumulation through
+    4 residual blocks -- 2e-2 of the output range, the CLIP trunk's tolerance."""
+    from veon_amd import _lib
+    g = load_golden('side_adapter_tiny')
+    trunk, head, net = _build(g)
+    dev = torch.device('cuda:0')
+    net = net.to(dev)
+    images = torch.from_numpy(g['images']).to(dev)
+    feats = {i: torch.from_numpy(g['clip_feat_%d' % i]).to(dev)
+             for i in range(CFG['clip_first_tail'] + 1)}      # the reference's CLIP maps
+    with torch.no_grad():
+        before = dict(_lib.CALLS)
+        mask_preds, attn_biases, san_feats = net(images, feats)
+        ran = {k: _lib.CALLS.get(k, 0) - before.get(k, 0)
+               for k in ('veon_vit_layernorm_padded', 'veon_vit_attention', 'veon_vit_gemm')}
+        net.vit_model.use_hip = False
+        ref_preds, ref_biases, ref_feats = net(images, feats)
+    depth = CFG['depth']
+    assert ran == {'veon_vit_layernorm_padded': 2 * depth, 'veon_vit_attention': depth,
+                   'veon_vit_gemm': 4 * depth}, ran
+    _close(mask_preds[0], g['mask_preds'], tol=2e-2)
+    _close(attn_biases[0][0], g['attn_bias'], tol=2e-2)
+    for i, f in enumerate(san_feats):
+        _close(f, g['san_feat_%d' % i], tol=2e-2)
+        _close(f, ref_feats[i].cpu().numpy(), tol=2e-2)
+    _close(mask_preds[0], ref_preds[0].cpu().numpy(), tol=2e-2)
+
+
+@pytest.mark.gpu
+def test_side_adapter_san_width_on_the_mfma_kernels():
+    """The SAN configuration itself (width 240, 6 heads of 40, 8 blocks, 100 queries) at
+    the bench resolution (256x704 -> 16x44 patches): native blocks against the fp32
+    PyTorch blocks on the same random weights, relative L2 <= 2e-2 per tapped map."""
+    torch.manual_seed(0)
+    dev = torch.device('cuda:0')
+    net = RegionwiseSideAdapterNetwork.build(clip_dim=768).to(dev).eval()
+    images = torch.randn(2, 3, 256, 704, device=dev)
+    feats = {i: torch.randn(2, 768, 8, 22, device=dev) for i in (0, 3, 6, 9)}
+    with torch.no_grad():
+        a_preds, a_bias, a_feats = net(images, feats)
+        net.vit_model.use_hip = False
+        b_preds, b_bias, b_feats = net(images, feats)
+    for x, y in zip(a_feats + a_preds, b_feats + b_preds):
+        rel = ((x - y).norm() / y.norm()).item()
+        assert rel <= 2e-2, rel
+    assert a_bias[0][0].shape == (2, 12, 100, 16, 44)
+
+
+@pytest.mark.gpu
 def test_2d_branch_on_the_gpu():
-    """Same chain on cuda:0: the CLIP trunk runs on the bf16 MFMA kernels there, the
-    side adapter in fp32 PyTorch.  Tolerance 3e-2 of the output range (bf16 operands,
+    """Same chain on cuda:0: the CLIP trunk and the side adapter's blocks run on the
+    MFMA kernels there.  Tolerance 3e-2 of the output range (bf16 operands,
     fp32 accumulation, 4 residual blocks)."""
     g = load_golden('side_adapter_tiny')
     trunk, head, net = _build(g)

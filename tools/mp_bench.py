@@ -7,7 +7,7 @@ the Conv3d body's padded input (what the VEON path runs) and fp32 -> fp32:
             a quarter of the pixels lie beyond the depth range and keep all their bins
   twohot45  the same with every pixel inside the depth range (U(1, 45))
 
-each with the azimuth chunk order (default) and the kernel's built-in order,
+each with the kernel's built-in chunk order (default) and the azimuth order,
 interleaved rounds in one process, HIP events; outputs compared bit for bit.
 
     python tools/mp_bench.py [rounds] [--tune]
@@ -48,28 +48,6 @@ def twohot_case(dev, hi, seed=0):
                 gsize=tuple(int(v) for v in vt.grid_size), keep=(vt, tw, ws))
 
 
-def graph_time(fn, reps=20):
-    """us per call, replayed from a hipGraph of `reps` calls (the two-stream fork / join
-    of the split launch costs host time eagerly; in the VEON path it lives in a graph)."""
-    s = torch.cuda.Stream()
-    s.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(s):
-        fn()
-    torch.cuda.current_stream().wait_stream(s)
-    g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g, stream=s):
-        for _ in range(reps):
-            fn()
-    g.replay()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
-    e0.record()
-    g.replay()
-    e1.record()
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / reps * 1e3
-
-
 def main():
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 5
     dev = torch.device('cuda:0')
@@ -89,15 +67,14 @@ def main():
         fb = cse['feat_nhwc'].to(vol.rows.dtype)
         alg_b = (fb.numel() * 2 + cse['depth'].numel() * 4 + 8 * cse['kept'] +
                  4 * (Z * Y * X + 1) + (Z * Y * X // 8) * C * 2)
-        for oname, o, split in (('builtin split', None, True), ('builtin fused', None, False),
-                                ('azimuth split', order, True)):
-            def run_b(cse=cse, fb=fb, o=o, split=split):
+        for oname, o in (('builtin', None), ('azimuth', order)):
+            def run_b(cse=cse, fb=fb, o=o):
                 bp.rows_maxpool(cse['depth'], fb, cse['rd'], cse['rf'], cse['vs'], shape,
-                                (2, 2, 2), out_volume=vol, chunk_order=o, split=split)
+                                (2, 2, 2), out_volume=vol, chunk_order=o)
 
-            def run_f(cse=cse, o=o, split=split):
+            def run_f(cse=cse, o=o):
                 return bp.rows_maxpool(cse['depth'], cse['feat_nhwc'], cse['rd'], cse['rf'],
-                                       cse['vs'], shape, (2, 2, 2), chunk_order=o, split=split)
+                                       cse['vs'], shape, (2, 2, 2), chunk_order=o)
             runs.append(('%s bf16 padded %s' % (tag, oname), run_b, alg_b, (tag, 'b')))
             runs.append(('%s f32 %s' % (tag, oname), run_f, None, (tag, 'f')))
     refs = {}
@@ -114,7 +91,7 @@ def main():
     res = {r[0]: [] for r in runs}
     for _ in range(rounds):
         for name, fn, _, _ in runs:
-            res[name].append(graph_time(fn))
+            res[name].append(timeit(fn, 20))
     for name, _, alg, key in runs:
         t = np.array(res[name])
         extra = ''

@@ -67,12 +67,8 @@ _SIGNATURES = {
     'veon_bev_pool_v2_fwd_rows_maxpool': (_ci, [_ci] * 8 + [_vp, _vp, _ci, _vp, _vp, _vp, _vp,
                                                 _ci, _i64, _vp]),
     'veon_bev_pool_rows_maxpool_chunk': (_ci, []),
-    'veon_pool_prof_read': (_ci, [_vp, _i64]),
-    'veon_pool_prof_read2': (_ci, [_vp, _i64]),
     'veon_bev_pool_v2_fwd_rows_maxpool_ordered': (_ci, [_ci] * 8 + [_vp, _vp, _ci, _vp, _vp, _vp,
                                                         _vp, _ci, _i64, _vp, _vp]),
-    'veon_bev_pool_v2_fwd_rows_maxpool_part': (_ci, [_ci] * 8 + [_vp, _vp, _ci, _vp, _vp, _vp,
-                                                     _vp, _ci, _i64, _vp, _ci, _vp]),
     'veon_bev_pool_plan_ints': (_i64, [_ci, _i64]),
     'veon_bev_pool_plan': (_ci, [_ci, _ci, _ci, _i64, _vp, _vp, _vp, _vp, _vp]),
     'veon_bev_pool_row_table': (_ci, [_ci, _ci, _ci, _i64, _ci, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -84,6 +80,7 @@ _SIGNATURES = {
     'veon_gemm_ring_set': (None, [_ci]),
     'veon_vit_cast_bf16': (_ci, [_vp, _vp, _i64, _vp]),
     'veon_vit_layernorm': (_ci, [_vp, _vp, _vp, _vp, _ci, _ci, _cf, _vp]),
+    'veon_vit_layernorm_padded': (_ci, [_vp, _vp, _vp, _vp, _ci, _ci, _ci, _cf, _vp]),
     'veon_vit_patchify': (_ci, [_vp, _vp] + [_ci] * 7 + [_vp]),
     'veon_vit_gemm': (_ci, [_vp] * 6 + [_ci] * 4 + [_vp]),
     'veon_vit_attention': (_ci, [_vp, _vp, _i64, _i64, _vp, _ci, _ci, _ci, _ci, _vp]),

@@ -370,24 +370,6 @@ constexpr int kColdDef = 64;   // measured on MI355X (tools/pool_tune.py)
 constexpr int kWarmDef = 256;
 constexpr int kWorkersDef = 512;
 constexpr int kCand = kMW * 64;        // candidates a worker looks at per pass
-constexpr int kSeg = 16;               // points per segment of a pipelined chain
-constexpr int kLists = 16;             // long lists a worker has in LDS at a time
-
-// tools/mp_prof.py only (debug bit 20): per-worker time stamps (100 MHz), list / chain /
-// point counts
-__device__ unsigned long long g_mp_prof[2048 * 8];
-__device__ unsigned long long g_mp_prof2[2048 * 8 * 4];
-__device__ unsigned long long g_mp_trace[256 * 8];  // worker (dbg >> 21): ta, tb, tc, td of its first 256 segments  // per (worker, wave): idx+issue, spin, compute, segments
-
-// order-preserving integer key of a float (not NaN): a < b  <=>  fkey(a) < fkey(b),
-// +0 above -0
-__device__ __forceinline__ int fkey(float v) {
-  const int b = __float_as_int(v);
-  return b >= 0 ? b : b ^ 0x7fffffff;
-}
-__device__ __forceinline__ float keyf(int k) {
-  return __int_as_float(k >= 0 ? k : k ^ 0x7fffffff);
-}
 
 template <int DZ, int DY, int DX>
 __device__ __forceinline__ int64_t seg_entry(int b, int zo, int yo, int xo, int g, int Z,
@@ -412,12 +394,7 @@ __device__ __forceinline__ float pooled_value(float m, int n_occ, int full) {
   return n_occ < full ? vmax(0.f, m) : m;  // m = -inf when nothing is occupied
 }
 
-// ROLE: 0 = workers (blockIdx < kWorkers) and cold workgroups in one launch; 1 = the
-// cold workgroups only (grid = chunks), 2 = the workers only (grid = kWorkers): two
-// launches that a caller runs side by side on two streams -- the workers' deep row
-// pipelines cost registers that halve the occupancy of the cold path when both live
-// in one kernel (measured: the fused launch 79 us, cold alone 42, workers alone 54).
-template <int FT, int DZ, int DY, int DX, int OUT, int ROLE>
+template <int FT, int DZ, int DY, int DX, int OUT>
 __global__ __launch_bounds__(kMW * 64) void k_rows_maxpool(
     const float* __restrict__ depth, const void* __restrict__ feat,
     const int* __restrict__ ranks_depth, const int* __restrict__ ranks_feat,
@@ -425,12 +402,9 @@ __global__ __launch_bounds__(kMW * 64) void k_rows_maxpool(
     void* __restrict__ outp, int dbg, int kWorkers, int kCold, int kWarm, int order,
     const int* __restrict__ chunk_order) {
   constexpr int NSEG = DZ * DY, GL = DX, NE = NSEG * (GL + 1), FULL = DZ * DY * DX;
-  constexpr int SEG = ROLE == 2 ? kSeg : kSeg / 2;   // points per pipelined segment
   static_assert(NE <= 16, "boundary entries of one pooled voxel must fit 16 lanes");
-  if (ROLE == 0 && dbg &&
-      (((dbg & 1) && blockIdx.x < kWorkers) || ((dbg & 2) && blockIdx.x >= kWorkers)))
+  if (dbg && (((dbg & 1) && blockIdx.x < kWorkers) || ((dbg & 2) && blockIdx.x >= kWorkers)))
     return;
-  const int cold0 = ROLE == 1 ? 0 : kWorkers;   // linear id of the first cold workgroup
   extern __shared__ int lds_i[];
   const int Zo = Z / DZ, Yo = Y / DY, Xo = X / DX;
   const int plane = Zo * Yo * Xo;                     // pooled voxels per batch element
@@ -443,76 +417,16 @@ __global__ __launch_bounds__(kMW * 64) void k_rows_maxpool(
                (int64_t)c;
   };
 
-  if (ROLE != 1 && (ROLE == 2 || blockIdx.x < kWorkers)) {
-    // ================= workers: the long lists =================
-    // Every pooled voxel with more than kCold points, kLists of them at a time.  The
-    // sum of one input voxel is a serial fmaf chain by contract -- but only the fmas
-    // are serial.  All chains of these lists are cut into segments of SEG points and
-    // laid out as ONE sequence; wave w takes segments w, w + kMW, ..., issues ALL
-    // loads of its segment at once (lanes = 4 consecutive channels: a full-width row
-    // per load); a segment that continues a chain then waits until its predecessor is
-    // done (fin[], LDS), takes the running sums over through LDS, adds its points in
-    // order and hands on; segments of different chains do not wait for each other.
-    // kMW * SEG rows are in flight per workgroup whatever chain or list they belong
-    // to (a load level costs ~1 us here: one chain or one list at a time spends its
-    // life waiting), and the ~50 cycles of vector work per point spread over the
-    // waves.  Same chains, same order, same bits.
-    // The <= FULL chain sums of a pooled voxel meet in LDS by an atomic max on
-    // order-preserving integer keys (a NaN sum is skipped, as `v > m` skips it); the
-    // wave that delivers a voxel's last chain writes the output row.
-    int* wlist = lds_i;                    // [kCand] long pooled ids (b*plane + lin)
-    int* ctr = wlist + kCand;              // [8] n_lists, token, q head, n_short, n_long
-    int* chs = ctr + 8;                    // [kLists*FULL] chain start
-    int* chl = chs + kLists * FULL;        // [kLists*FULL] chain length
-    int* sgo = chl + kLists * FULL;        // [kLists*FULL] inclusive prefix of segments
-    int* lneed = sgo + kLists * FULL;      // [kLists] non-empty chains of the list
-    int* ldone = lneed + kLists;           // [kLists] chains delivered
-    int* fin = ldone + kLists;             // [16] fin[s & 15] >= s: segment s is done
-    float* hacc = reinterpret_cast<float*>(fin + 16);         // [8][256] running sums
-    int* hm = reinterpret_cast<int*>(hacc + 8 * 256);         // [kLists][256] max keys
-    const int kminkey = fkey(kmin);
-    // deliver the sum of chain entry e (4 channels per lane); maybe finish its voxel
-    auto deliver = [&](int e, const float* acc, int c0, int ch, bool chact) {
-      const int li = e / FULL;
-      if (chact) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-          if (acc[k] == acc[k]) atomicMax(&hm[li * 256 + lane * 4 + k], fkey(acc[k]));
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      int d = 0;
-      if (lane == 0) d = atomicAdd(&ldone[li], 1) + 1;
-      d = uni(d);
-      const int need = lneed[li];
-      if (d != need) return;
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-      const int pid = wlist[ctr[5] + li];
-      const int b = pid / plane;
-      const int lin = pid - b * plane;
-      if (!chact) return;
-      float v[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k)
-        v[k] = pooled_value(keyf(hm[li * 256 + lane * 4 + k]), need, FULL);
-      if constexpr (OUT == 1) {
-        *reinterpret_cast<uint2*>(out_row(b, lin) + ch) = pack_bf16x4(v);
-      } else {
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-          static_cast<float*>(outp)[((int64_t)b * c + ch + k) * plane + lin] = v[k];
-      }
-    };
+  if (blockIdx.x < kWorkers) {
+    // ================= workers: warm and hot lists =================
+    int* wlist = lds_i;                  // [kCand] warm pooled ids (b*plane + lin)
+    int* hlist = wlist + kCand;          // [kCand] hot pooled ids
+    int* ctr = hlist + kCand;            // [4] n_warm, n_hot, pulled, pad
+    int* ctab = ctr + 4;                 // [FULL][2] chain start, length
+    float* hkey = reinterpret_cast<float*>(ctab + 2 * FULL);  // [FULL][256] sums
     const int64_t total = (int64_t)batch * plane;
-    const bool prof = (dbg & (1 << 20)) && threadIdx.x == 0 && blockIdx.x < 2048;
-    unsigned long long* pr = g_mp_prof + blockIdx.x * 8;
-    if (prof) {
-      pr[0] = __builtin_amdgcn_s_memrealtime();
-      pr[3] = __builtin_readcyclecounter();
-      pr[4] = pr[5] = pr[6] = pr[7] = 0;
-    }
-
     for (int64_t pass0 = 0; pass0 < total; pass0 += (int64_t)kWorkers * kCand) {
-      if (threadIdx.x < 8) ctr[threadIdx.x] = 0;
+      if (threadIdx.x < 4) ctr[threadIdx.x] = 0;
       __syncthreads();
       {
         const int64_t pid = pass0 + blockIdx.x + (int64_t)threadIdx.x * kWorkers;
@@ -526,193 +440,161 @@ __global__ __launch_bounds__(kMW * 64) void k_rows_maxpool(
             const int64_t e = seg_entry<DZ, DY, DX>(b, zo, yo, xo, g, Z, Y, X);
             n += vstart[e + GL] - vstart[e];
           }
-          const bool skip = (n > kWarm) ? (dbg & 8) : (dbg & 4);  // ablation knobs
-          if (n > kCold && !skip) wlist[atomicAdd(&ctr[0], 1)] = (int)pid;
+          if (n > kWarm && !(dbg & 8)) hlist[atomicAdd(&ctr[1], 1)] = (int)pid;
+          else if (n > kCold && !(dbg & 4)) wlist[atomicAdd(&ctr[0], 1)] = (int)pid;
         }
       }
       __syncthreads();
-      const int nlist = ctr[0];
-      if (prof) {
-        pr[1] = __builtin_amdgcn_s_memrealtime();
-        pr[4] += nlist;
-      }
-      for (int l0 = 0; l0 < nlist; l0 += kLists) {
-        const int nl = (nlist - l0) < kLists ? (nlist - l0) : kLists;
-        const int ne = nl * FULL;
-        // ---- chain table of these lists + exclusive prefix of their segment counts
-        if (threadIdx.x < kLists * FULL) {
-          int len = 0;
-          if (threadIdx.x < ne) {
-            const int li = threadIdx.x / FULL, q = threadIdx.x - li * FULL;
-            const int pid = wlist[l0 + li];
-            const int b = pid / plane;
-            const int lin = pid - b * plane;
-            const int xo = lin % Xo, yo = (lin / Xo) % Yo, zo = lin / (Xo * Yo);
-            const int g = q / GL, k = q - g * GL;
-            const int64_t e = seg_entry<DZ, DY, DX>(b, zo, yo, xo, g, Z, Y, X) + k;
-            const int pa = vstart[e];
-            len = vstart[e + 1] - pa;
-            chs[threadIdx.x] = pa;
-          }
-          chl[threadIdx.x] = len;
-          sgo[threadIdx.x] = (len + SEG - 1) / SEG;
-        }
-        __syncthreads();
-        // (kLists * FULL = 128 entries: two waves; Hillis-Steele in LDS)
-        for (int off = 1; off < kLists * FULL; off <<= 1) {
-          int add = 0;
-          if (threadIdx.x < kLists * FULL && threadIdx.x >= off) add = sgo[threadIdx.x - off];
-          __syncthreads();
-          if (threadIdx.x < kLists * FULL) sgo[threadIdx.x] += add;
-          __syncthreads();
-        }
-        const int nsg = sgo[kLists * FULL - 1];   // inclusive prefix: total segments
-        if (prof) {
-          pr[5] += ne;
-          pr[6] += nsg;
+      const int nwarm = ctr[0], nhot = ctr[1];
+      // ---- hot: the workgroup on one pooled voxel, tasks = (input voxel, quarter)
+      for (int hi = 0; hi < nhot; ++hi) {
+        const int pid = hlist[hi];
+        const int b = pid / plane;
+        const int lin = pid - b * plane;
+        const int xo = lin % Xo, yo = (lin / Xo) % Yo, zo = lin / (Xo * Yo);
+        if (threadIdx.x < FULL) {
+          const int g = threadIdx.x / GL, k = threadIdx.x - g * GL;
+          const int64_t e = seg_entry<DZ, DY, DX>(b, zo, yo, xo, g, Z, Y, X) + k;
+          const int pa = vstart[e];
+          ctab[2 * threadIdx.x] = pa;
+          ctab[2 * threadIdx.x + 1] = vstart[e + 1] - pa;
         }
         for (int c0 = 0; c0 < c; c0 += 256) {
-          if (threadIdx.x == 0) ctr[5] = l0;
-          if (threadIdx.x < 16) fin[threadIdx.x] = -1;
-          if (threadIdx.x < nl) {
-            int need = 0;
-#pragma unroll
-            for (int q = 0; q < FULL; ++q) need += chl[threadIdx.x * FULL + q] > 0;
-            lneed[threadIdx.x] = need;
-            ldone[threadIdx.x] = 0;
-          }
-          for (int i = threadIdx.x; i < nl * 256; i += kMW * 64) hm[i] = kminkey;
+          if (threadIdx.x == 0) ctr[2] = 0;
           __syncthreads();
-          const int ch = c0 + lane * 4;
-          const bool chact = ch < c;
-          const int chl0 = chact ? ch : 0;
-          // ---- ONE sequence of segments over all chains of these lists: wave w takes
-          //      segments w, w + kMW, ...; the loads of a segment are issued at once, the
-          //      fmas wait for the token (= segments done), so the waves always have the
-          //      rows of the next kMW segments in flight whatever chain they belong to
-          for (int sg = w; sg < nsg; sg += kMW) {
-            const bool tr = (dbg & (1 << 20)) && blockIdx.x == (unsigned)(dbg >> 21) &&
-                            lane == 0 && sg < 256 && l0 == 0;
-            const unsigned long long ta = tr ? __builtin_amdgcn_s_memrealtime() : 0;
-            // entry e: sgo[e-1] <= sg < sgo[e]  (inclusive prefix; binary search, uniform)
-            int lo = 0, hi = kLists * FULL - 1;
-            while (lo < hi) {
-              const int mid = (lo + hi) >> 1;
-              if (sgo[mid] <= sg) lo = mid + 1;
-              else hi = mid;
+          for (;;) {
+            int ti = 0;
+            if (lane == 0) ti = atomicAdd(&ctr[2], 1);
+            ti = uni(ti);
+            if (ti >= FULL * 4) break;
+            const int q = ti >> 2, h = ti & 3;
+            const int pa = ctab[2 * q], n = ctab[2 * q + 1];
+            const int ch = c0 + h * 64 + lane;
+            if (n == 0 || c0 + h * 64 >= c) continue;  // uniform
+            const int chl = ch < c ? ch : 0;
+            float acc = 0.f;
+            int rfn = 0;
+            float dn = 0.f;
+            if (lane < n) {
+              rfn = ranks_feat[pa + lane] * c;
+              dn = depth[ranks_depth[pa + lane]];
             }
-            // (LDS values are wave-uniform here; tell the compiler, or every `u < ns`
-            //  below becomes an exec-mask branch: 70 cycles per step, measured)
-            const int e = uni(lo);
-            const int i = uni(sg - (e > 0 ? sgo[e - 1] : 0));   // segment inside its chain
-            const int len = uni(chl[e]);
-            const int pa = uni(chs[e]) + i * SEG;
-            const int ns = (len - i * SEG) < SEG ? (len - i * SEG) : SEG;
-            int rfj = 0;
-            float dj = 0.f;
-            if (lane < ns) {
-              rfj = ranks_feat[pa + lane] * c;
-              dj = depth[ranks_depth[pa + lane]];
-            }
-            typename RawN<FT, 4>::T raw[SEG];
-#pragma unroll
-            for (int u = 0; u < SEG; ++u) {
-              const int kk = u < ns ? u : ns - 1;  // the tail re-reads the last row
-              raw[u] = loadn<FT, 4>(feat, (int64_t)rl(rfj, kk) + chl0);
-            }
-            const unsigned long long tb = tr ? __builtin_amdgcn_s_memrealtime() : 0;
-            // ---- a segment that continues a chain waits for its predecessor (the row
-            //      loads above stay in flight meanwhile) and takes the running sums over
-            if (i > 0)
-              while (__hip_atomic_load(&fin[(sg - 1) & 15], __ATOMIC_ACQUIRE,
-                                       __HIP_MEMORY_SCOPE_WORKGROUP) < sg - 1)
-                __builtin_amdgcn_s_sleep(1);
-            const unsigned long long tc = tr ? __builtin_amdgcn_s_memrealtime() : 0;
-            float acc[4] = {0.f, 0.f, 0.f, 0.f};
-            if (i > 0) {
-              const float4 a =
-                  *reinterpret_cast<const float4*>(hacc + ((sg - 1) & 7) * 256 + lane * 4);
-              acc[0] = a.x; acc[1] = a.y; acc[2] = a.z; acc[3] = a.w;
-            }
-            unsigned long long tm0 = 0, tm1 = 0;
-            if (ns == SEG) {   // full segment: straight-line code
-#pragma unroll
-              for (int u = 0; u < SEG; ++u) {
-                float f[4];
-                cvtn<FT, 4>(raw[u], f);
-                const float d = rlf(dj, u);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) acc[k] = fmaf(f[k], d, acc[k]);
+            for (int base = 0; base < n; base += kWave) {
+              const int rfv = rfn;
+              const float dj = dn;
+              const int nb = (n - base) < kWave ? (n - base) : kWave;
+              const int qn = base + kWave + lane;
+              rfn = 0;
+              dn = 0.f;
+              if (qn < n) {
+                rfn = ranks_feat[pa + qn] * c;
+                dn = depth[ranks_depth[pa + qn]];
               }
-            } else {   // partial segment: the same steps, results selected (no branches)
+              gather_batch<FT, 1, 32>(feat, c, chl, rfv, nb, [&](int kk, const float* f) {
+                acc = fmaf(f[0], rlf(dj, kk), acc);
+              });
+            }
+            hkey[q * 256 + h * 64 + lane] = acc;
+          }
+          __syncthreads();
+          if (threadIdx.x < 256 && c0 + threadIdx.x < c) {
+            const int cc = threadIdx.x;
+            float m = kmin;
+            int n_occ = 0;
 #pragma unroll
-              for (int u = 0; u < SEG - 1; ++u) {
-                float f[4];
-                cvtn<FT, 4>(raw[u], f);
-                const float d = rlf(dj, u);
-                const bool on = u < ns;   // wave-uniform
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                  const float t = fmaf(f[k], d, acc[k]);
-                  acc[k] = on ? t : acc[k];
-                }
+            for (int q = 0; q < FULL; ++q)
+              if (ctab[2 * q + 1] > 0) {
+                m = vmax(m, hkey[q * 256 + cc]);
+                ++n_occ;
               }
-            }
-            if (tr) {
-              asm volatile("" :: "v"(acc[0]));
-              tm1 = __builtin_amdgcn_s_memrealtime();
-              tm0 = tm1;
-            }
-            if ((i + 1) * SEG < len) {
-              // hand-over slot sg & 7 was last read by segment sg - 7: it must be done
-              if (sg >= 7)
-                while (__hip_atomic_load(&fin[(sg - 7) & 15], __ATOMIC_ACQUIRE,
-                                         __HIP_MEMORY_SCOPE_WORKGROUP) < sg - 7)
-                  __builtin_amdgcn_s_sleep(1);
-              *reinterpret_cast<float4*>(hacc + (sg & 7) * 256 + lane * 4) =
-                  make_float4(acc[0], acc[1], acc[2], acc[3]);
-            } else {
-              deliver(e, acc, c0, ch, chact);   // chain complete
-            }
-            __hip_atomic_store(&fin[sg & 15], sg, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (tr) {
-              unsigned long long* t4 = g_mp_trace + sg * 8;
-              t4[0] = ta;
-              t4[1] = tb;
-              t4[2] = tc;
-              t4[3] = __builtin_amdgcn_s_memrealtime();
-              t4[4] = tm0;
-              t4[5] = tm1;
-              t4[6] = ns;
-              t4[7] = (unsigned long long)i;
-            }
+            const float v = pooled_value(m, n_occ, FULL);
+            if constexpr (OUT == 1)
+              out_row(b, lin)[c0 + cc] = __builtin_bit_cast(unsigned short, (veon_half_native)v);
+            else
+              static_cast<float*>(outp)[((int64_t)b * c + c0 + cc) * plane + lin] = v;
           }
           __syncthreads();
         }
       }
+      // ---- warm: one wave per list, pulled from the queue
+      if (threadIdx.x == 0) ctr[2] = 0;
       __syncthreads();
-    }
-    if (prof) {
-      pr[2] = __builtin_amdgcn_s_memrealtime();
-      pr[3] = __builtin_readcyclecounter() - pr[3];
+      for (;;) {
+        int wi = 0;
+        if (lane == 0) wi = atomicAdd(&ctr[2], 1);
+        wi = uni(wi);
+        if (wi >= nwarm) break;
+        const int pid = wlist[wi];
+        const int b = pid / plane;
+        const int lin = pid - b * plane;
+        const int xo = lin % Xo, yo = (lin / Xo) % Yo, zo = lin / (Xo * Yo);
+        int vs = 0;
+        if (lane < NE) {
+          const int g = lane / (GL + 1), k = lane - g * (GL + 1);
+          vs = vstart[seg_entry<DZ, DY, DX>(b, zo, yo, xo, g, Z, Y, X) + k];
+        }
+        const int vnext = __shfl_down(vs, 1);
+        const int n_occ = __popcll(__ballot(lane < NE && (lane % (GL + 1)) < GL && vnext > vs));
+        const RunTab rt = run_table<NSEG, GL>(vs, 0, lane);
+        const int n = rl(rt.ce, NSEG - 1);
+        for (int c0 = 0; c0 < c; c0 += 256) {
+          const int ch = c0 + lane * 4;
+          const bool chact = ch < c;
+          const int chl = chact ? ch : 0;
+          float acc[4] = {0.f, 0.f, 0.f, 0.f};
+          float m[4] = {kmin, kmin, kmin, kmin};
+          for (int base = 0; base < n; base += kWave) {
+            const Stage1 st = stage1<NSEG, GL>(rt, vs, 0, base, n, lane);
+            int rfj = 0;
+            float dj = 0.f;
+            if (st.act) {
+              rfj = ranks_feat[st.p] * c;
+              dj = depth[ranks_depth[st.p]];
+            }
+            gather_batch<FT, 4, kRing>(feat, c, chl, rfj, st.nb, [&](int kk, const float* f) {
+              const float d = rlf(dj, kk);
+#pragma unroll
+              for (int k = 0; k < 4; ++k) acc[k] = fmaf(f[k], d, acc[k]);
+              if ((st.last >> kk) & 1ull) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                  m[k] = vmax(m[k], acc[k]);
+                  acc[k] = 0.f;
+                }
+              }
+            });
+          }
+          float v[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) v[k] = pooled_value(m[k], n_occ, FULL);
+          if (chact) {
+            if constexpr (OUT == 1) {
+              *reinterpret_cast<uint2*>(out_row(b, lin) + ch) = pack_bf16x4(v);
+            } else {
+#pragma unroll
+              for (int k = 0; k < 4; ++k)
+                static_cast<float*>(outp)[((int64_t)b * c + ch + k) * plane + lin] = v[k];
+            }
+          }
+        }
+      }
+      __syncthreads();
     }
     return;
   }
 
   // ================= cold workgroups =================
-  if constexpr (ROLE == 2) return;
   float* tile = reinterpret_cast<float*>(lds_i);  // OUT == 0: [256][kPV + 1]
   int* hotf = lds_i + 256 * (kPV + 1);            // OUT == 0: [kPV] column is not cold
   const int chunks = (plane + kPV - 1) / kPV;
   // cold workgroup -> chunk of pooled voxels in XCD-grouped order (the linear id
   // of cold workgroup i is kWorkers + i, kWorkers a multiple of 8)
-  // (or the caller's order: a permutation of the chunks, e.g. sorted by azimuth
-  // around the rig so that the chunks one XCD gets see the rays of one or two
-  // cameras and its L2 holds their feature rows -- veon_bev_pool_v2_fwd_rows_maxpool_ordered)
+  // (or the caller's order, a permutation of the chunks:
+  //  veon_bev_pool_v2_fwd_rows_maxpool_ordered)
   const int64_t cw = chunk_order != nullptr
-                         ? (int64_t)chunk_order[blockIdx.x - cold0]
-                         : xcd_grouped((int64_t)blockIdx.x - cold0,
-                                       (int64_t)gridDim.x - cold0, order);
+                         ? (int64_t)chunk_order[blockIdx.x - kWorkers]
+                         : xcd_grouped((int64_t)blockIdx.x - kWorkers,
+                                       (int64_t)gridDim.x - kWorkers, order);
   const int b = (int)(cw / chunks);
   const int lin0 = (int)(cw - (int64_t)b * chunks) * kPV;
 
@@ -1165,25 +1047,11 @@ int veon_bev_pool_v2_fwd_rows(int c, int batch, int64_t voxels_per_batch,
 
 int veon_bev_pool_rows_maxpool_chunk(void) { return kPV; }
 
-int veon_pool_prof_read(void* dst_host, int64_t bytes) {
-  if (!dst_host || bytes <= 0 || bytes > (int64_t)sizeof(unsigned long long) * 2048 * 8)
-    return VEON_ERR_BAD_ARG;
-  return hipMemcpyFromSymbol(dst_host, HIP_SYMBOL(g_mp_prof), (size_t)bytes, 0,
-                             hipMemcpyDeviceToHost) == hipSuccess ? VEON_OK : VEON_ERR_LAUNCH;
-}
-int veon_pool_prof_read2(void* dst_host, int64_t bytes) {
-  if (!dst_host || bytes <= 0 || bytes > (int64_t)sizeof(unsigned long long) * 256 * 8)
-    return VEON_ERR_BAD_ARG;
-  return hipMemcpyFromSymbol(dst_host, HIP_SYMBOL(g_mp_trace), (size_t)bytes, 0,
-                             hipMemcpyDeviceToHost) == hipSuccess ? VEON_OK : VEON_ERR_LAUNCH;
-}
-
-int veon_bev_pool_v2_fwd_rows_maxpool_part(
+int veon_bev_pool_v2_fwd_rows_maxpool_ordered(
     int c, int batch, int Z, int Y, int X, int dz, int dy, int dx, const float* depth,
     const void* feat, int feat_dtype, const int* ranks_depth, const int* ranks_feat,
     const int* vstart, void* out, int out_padded_bf16, int64_t feat_elems,
-    const int* chunk_order, int part, void* stream) {
-  if (part < 0 || part > 2) return VEON_ERR_BAD_ARG;
+    const int* chunk_order, void* stream) {
   if (c <= 0 || (c & 3) || batch <= 0 || Z <= 0 || Y <= 0 || X <= 0 || !depth ||
       !feat || !vstart || !out)
     return VEON_ERR_BAD_ARG;
@@ -1201,56 +1069,33 @@ int veon_bev_pool_v2_fwd_rows_maxpool_part(
   const int kWorkers = g_pool_workers > 0 ? g_pool_workers : kWorkersDef;
   const int kCold = g_pool_cold > 0 ? g_pool_cold : kColdDef;
   const int kWarm = g_pool_warm > 0 ? g_pool_warm : kWarmDef;
-  const int64_t n_cold = (int64_t)batch * ((plane + kPV - 1) / kPV);
-  const int64_t wgs = part == 1 ? n_cold : part == 2 ? kWorkers : kWorkers + n_cold;
+  const int64_t wgs = kWorkers + (int64_t)batch * ((plane + kPV - 1) / kPV);
   if (wgs > 0x7fffffffLL) return VEON_ERR_BAD_ARG;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  // workers: candidate list + chain table + running sums + 8 x 256 chain sums; cold
-  // (fp32 planar): transpose tile
-  const size_t lds_hot =
-      (size_t)(kCand + 8 + 3 * kLists * 8 + 2 * kLists + 16 + 8 * 256 + kLists * 256) *
-      sizeof(int);
+  // hot workers: candidate list + 8 x 256 keys; cold (fp32 planar): transpose tile
+  const size_t lds_hot = (size_t)(2 * kCand + 4 + 2 * 8 + 8 * 256) * sizeof(int);
   const size_t lds_cold = (size_t)(256 * (kPV + 1) + kPV) * sizeof(float);
   const size_t lds_cf = lds_cold > lds_hot ? lds_cold : lds_hot;
-#define VEON_ROWS_MP_R(FT, ROLE)                                                    \
+#define VEON_ROWS_MP(FT)                                                            \
   do {                                                                              \
     if (out_padded_bf16)                                                            \
-      hipLaunchKernelGGL((k_rows_maxpool<FT, 2, 2, 2, 1, ROLE>), dim3((unsigned)wgs), \
-                         dim3(kMW * 64), ROLE == 1 ? 0 : lds_hot, s, depth, feat,    \
-                         ranks_depth,                                               \
+      hipLaunchKernelGGL((k_rows_maxpool<FT, 2, 2, 2, 1>), dim3((unsigned)wgs), \
+                         dim3(kMW * 64), lds_hot, s, depth, feat, ranks_depth,       \
                          ranks_feat, vstart, c, batch, Z, Y, X, out, g_pool_debug,  \
                          kWorkers, kCold, kWarm, tile_order_lg(g_pool_debug, kOrderMp), \
                          chunk_order);                                              \
     else                                                                            \
-      hipLaunchKernelGGL((k_rows_maxpool<FT, 2, 2, 2, 0, ROLE>), dim3((unsigned)wgs), \
-                         dim3(kMW * 64), ROLE == 1 ? lds_cold : ROLE == 2 ? lds_hot : lds_cf, s, \
-                         depth, feat, ranks_depth,                                  \
+      hipLaunchKernelGGL((k_rows_maxpool<FT, 2, 2, 2, 0>), dim3((unsigned)wgs), \
+                         dim3(kMW * 64), lds_cf, s, depth, feat, ranks_depth,        \
                          ranks_feat, vstart, c, batch, Z, Y, X, out, g_pool_debug,  \
                          kWorkers, kCold, kWarm, tile_order_lg(g_pool_debug, kOrderMp), \
                          chunk_order);                                              \
   } while (0)
-#define VEON_ROWS_MP(FT)                      \
-  do {                                        \
-    if (part == 1) VEON_ROWS_MP_R(FT, 1);     \
-    else if (part == 2) VEON_ROWS_MP_R(FT, 2); \
-    else VEON_ROWS_MP_R(FT, 0);               \
-  } while (0)
   if (feat_dtype == VEON_FEAT_F32) VEON_ROWS_MP(VEON_FEAT_F32);
   else if (feat_dtype == VEON_FEAT_F16) VEON_ROWS_MP(VEON_FEAT_F16);
   else VEON_ROWS_MP(VEON_FEAT_BF16);
-#undef VEON_ROWS_MP_R
 #undef VEON_ROWS_MP
   return launch_status();
-}
-
-int veon_bev_pool_v2_fwd_rows_maxpool_ordered(
-    int c, int batch, int Z, int Y, int X, int dz, int dy, int dx, const float* depth,
-    const void* feat, int feat_dtype, const int* ranks_depth, const int* ranks_feat,
-    const int* vstart, void* out, int out_padded_bf16, int64_t feat_elems,
-    const int* chunk_order, void* stream) {
-  return veon_bev_pool_v2_fwd_rows_maxpool_part(
-      c, batch, Z, Y, X, dz, dy, dx, depth, feat, feat_dtype, ranks_depth, ranks_feat,
-      vstart, out, out_padded_bf16, feat_elems, chunk_order, 0, stream);
 }
 
 int veon_bev_pool_v2_fwd_rows_maxpool(int c, int batch, int Z, int Y, int X, int dz,

@@ -72,6 +72,52 @@ __global__ __launch_bounds__(256) void k_layernorm(
   }
 }
 
+// Rows of `ld` floats of which the first d are the token (the rest is padding that the
+// GEMMs need: K and N in multiples of 64): statistics over d, padding written as zeros.
+// The side-adapter ViT of SAN has d = 240 (side_adaptor_in_veon.py:194-241).
+__global__ __launch_bounds__(256) void k_layernorm_padded(
+    const float* __restrict__ x, const float* __restrict__ gamma,
+    const float* __restrict__ beta, bf16_t* __restrict__ out, int T, int d, int ld,
+    float eps) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= T) return;
+  const float* xr = x + (int64_t)row * ld;
+  float v[kLnMaxPerLane];
+  float s = 0.f;
+  const int n = (ld + 63) / 64;
+#pragma unroll
+  for (int i = 0; i < kLnMaxPerLane; ++i) {
+    if (i < n) {
+      const int c = i * 64 + lane;
+      v[i] = c < d ? xr[c] : 0.f;
+      s += v[i];
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+  const float mean = s / (float)d;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < kLnMaxPerLane; ++i) {
+    if (i < n) {
+      const int c = i * 64 + lane;
+      const float t = c < d ? v[i] - mean : 0.f;
+      q += t * t;
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) q += __shfl_xor(q, off);
+  const float rstd = rsqrtf(q / (float)d + eps);
+  bf16_t* o = out + (int64_t)row * ld;
+#pragma unroll
+  for (int i = 0; i < kLnMaxPerLane; ++i) {
+    if (i < n) {
+      const int c = i * 64 + lane;
+      if (c < d) o[c] = f2bf((v[i] - mean) * rstd * gamma[c] + beta[c]);
+      else if (c < ld) o[c] = f2bf(0.f);
+    }
+  }
+}
+
 // Vector form for d % 256 == 0 (ViT-B/L: 768, 1024): a lane owns float4 chunks
 // c = 4*(i*64 + lane), so the row comes in by 16-byte loads (1 KiB per wave
 // instruction) and leaves by 8-byte bf16x4 stores.  Same arithmetic order per
@@ -1011,6 +1057,18 @@ int veon_vit_layernorm(const float* x, const float* gamma, const float* beta,
     hipLaunchKernelGGL(k_layernorm_v4<1>, grid, dim3(256), 0, s, x, gamma, beta, o, T, eps);
   else
     hipLaunchKernelGGL(k_layernorm, grid, dim3(256), 0, s, x, gamma, beta, o, T, d, eps);
+  return launch_status();
+}
+
+int veon_vit_layernorm_padded(const float* x, const float* gamma, const float* beta,
+                              void* out_bf16, int T, int d, int ld, float eps,
+                              void* stream) {
+  if (T <= 0 || d <= 0 || ld < d || ld > 64 * kLnMaxPerLane || !x || !gamma || !beta ||
+      !out_bf16)
+    return VEON_ERR_BAD_ARG;
+  hipLaunchKernelGGL(k_layernorm_padded, dim3((unsigned)((T + 3) / 4)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), x, gamma, beta,
+                     static_cast<bf16_t*>(out_bf16), T, d, ld, eps);
   return launch_status();
 }
 

@@ -9,9 +9,13 @@ tokens; CLIP feature maps are added in at blocks 0 / 1 / 2 / 3 (``AddFusion``); 
 query and patch tokens of the last block feed ``MLPMaskDecoder``: mask proposals
 (B, Q, h, w) and per-head attention biases (B, heads, Q, h, w) for the CLIP
 recognition head.  The 3-D occupancy path takes nothing but a SHAPE from this branch
-(``sem_embed_ds``), so it is optional in ``VeonOccupancyPath`` (``side_adapter=True``)
-and plain PyTorch: head_dim 40 and K = 240 do not map onto the 64-wide MFMA tiles of
-csrc/vit_block.hip, and the branch is 0.1 TFLOP per image.
+(``sem_embed_ds``), so it is optional in ``VeonOccupancyPath`` (``side_adapter=True``).
+At inference on a ROCm device the eight blocks run on the MFMA kernels of
+csrc/vit_block.hip (``_native_blocks``): width 240 and head_dim 40 do not fit their
+64-wide tiles as they are, so the residual stream is padded to 256 columns and every
+head to 64 (zero weight rows / columns, packed once; q still scaled by 40^-0.5, so the
+softmax is unchanged), LayerNorm takes its statistics over the 240 real columns
+(``veon_vit_layernorm_padded``).
 
 Parameter names follow the reference (and timm's VisionTransformer for
 ``vit_model.*``: ``patch_embed.proj``, ``pos_embed``, ``blocks.N.norm1 / attn.qkv /
@@ -122,9 +126,71 @@ class _Block(nn.Module):
         return x + self.mlp(self.norm2(x))
 
 
+def _pad64(n):
+    return (n + 63) // 64 * 64
+
+
+class _PaddedBlock:
+    """One ``_Block`` packed for the MFMA kernels: width d -> dp = ceil64(d), every
+    head hd -> 64, MLP width -> ceil64; zero rows / columns in the padding, q rows
+    pre-scaled by hd^-0.5 (the attention kernel's contract).  Half-precision weights
+    [out, in], fp32 vectors."""
+
+    def __init__(self, blk, dev):
+        from ... import vit_ops
+        d = blk.norm1.weight.numel()
+        H = blk.attn.num_heads
+        hd = d // H
+        dp, m = _pad64(d), blk.mlp.fc1.out_features
+        mp = _pad64(m)
+        f32 = dict(dtype=torch.float32, device=dev)
+        wq = torch.zeros(3, H, 64, dp, **f32)
+        bq = torch.zeros(3, H, 64, **f32)
+        wq[:, :, :hd, :d] = blk.attn.qkv.weight.detach().float().view(3, H, hd, d)
+        bq[:, :, :hd] = blk.attn.qkv.bias.detach().float().view(3, H, hd)
+        wq[0] *= hd ** -0.5
+        bq[0] *= hd ** -0.5
+        wp = torch.zeros(dp, H, 64, **f32)
+        wp[:d, :, :hd] = blk.attn.proj.weight.detach().float().view(d, H, hd)
+        w1 = torch.zeros(mp, dp, **f32)
+        w1[:m, :d] = blk.mlp.fc1.weight.detach().float()
+        w2 = torch.zeros(dp, mp, **f32)
+        w2[:d, :m] = blk.mlp.fc2.weight.detach().float()
+
+        def vec(t, n):
+            o = torch.zeros(n, **f32)
+            o[:t.numel()] = t.detach().float().view(-1)
+            return o
+        self.d, self.dp, self.heads = d, dp, H
+        self.n1 = (vec(blk.norm1.weight, dp), vec(blk.norm1.bias, dp), blk.norm1.eps)
+        self.n2 = (vec(blk.norm2.weight, dp), vec(blk.norm2.bias, dp), blk.norm2.eps)
+        self.w_qkv = vit_ops.to_bf16(wq.view(3 * H * 64, dp))
+        self.b_qkv = bq.view(-1).contiguous()
+        self.w_proj = vit_ops.to_bf16(wp.view(dp, H * 64))
+        self.b_proj = vec(blk.attn.proj.bias, dp)
+        self.w_fc1, self.b_fc1 = vit_ops.to_bf16(w1), vec(blk.mlp.fc1.bias, mp)
+        self.w_fc2, self.b_fc2 = vit_ops.to_bf16(w2), vec(blk.mlp.fc2.bias, dp)
+
+    def forward_(self, s, B, T):
+        """x += attn(norm1(x)); x += mlp(norm2(x)) on the padded fp32 stream s
+        [B*T, dp], in place: seven launches (LayerNorm, qkv GEMM, attention, proj GEMM
+        onto the stream, LayerNorm, fc1 GEMM + GELU, fc2 GEMM onto the stream)."""
+        from ... import vit_ops
+        h = vit_ops.layernorm_padded(s, self.n1[0], self.n1[1], self.d, self.n1[2])
+        qkv = vit_ops.linear(h, self.w_qkv, self.b_qkv)
+        o = vit_ops.attention(qkv.view(B, T, -1), self.heads)
+        vit_ops.linear_residual_(s, o.view(B * T, -1), self.w_proj, self.b_proj)
+        h = vit_ops.layernorm_padded(s, self.n2[0], self.n2[1], self.d, self.n2[2])
+        u = vit_ops.linear(h, self.w_fc1, self.b_fc1, vit_ops.EPI_GELU)
+        vit_ops.linear_residual_(s, u, self.w_fc2, self.b_fc2)
+        return s
+
+
 class SideAdapterViT(nn.Module):
     """The timm VisionTransformer as SAN leaves it (side_adaptor_in_veon.py:103-112:
     class token dropped from ``pos_embed``, output norm replaced by Identity)."""
+
+    use_hip = True   # inference on a ROCm device: blocks on the MFMA kernels
 
     def __init__(self, img_size=640, patch_size=16, embed_dim=240, depth=8, num_heads=6):
         super().__init__()
@@ -136,6 +202,36 @@ class SideAdapterViT(nn.Module):
         self.norm_pre = nn.Identity()
         self.blocks = nn.Sequential(*[_Block(embed_dim, num_heads) for _ in range(depth)])
         self.norm = nn.Identity()
+        self.__dict__['_packed'] = None
+
+    def packed_blocks(self, dev):
+        """The blocks packed for the native path (cached with the half flavour they
+        were packed in; dropped by train() / load_state_dict() / .to())."""
+        from ... import half as _half
+        pk = self.__dict__['_packed']
+        if pk is None or pk[0] != (str(dev), _half.name()):
+            pk = ((str(dev), _half.name()), [_PaddedBlock(b, dev) for b in self.blocks])
+            self.__dict__['_packed'] = pk
+        return pk[1]
+
+    def native_ok(self, x):
+        return (self.use_hip and x.is_cuda and not self.training
+                and not torch.is_grad_enabled())
+
+    def invalidate_hip_cache(self):
+        self.__dict__['_packed'] = None
+
+    def train(self, mode=True):
+        self.__dict__['_packed'] = None
+        return super().train(mode)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self.__dict__['_packed'] = None
+        return super()._load_from_state_dict(*args, **kwargs)
+
+    def _apply(self, fn, *args, **kwargs):
+        self.__dict__['_packed'] = None
+        return super()._apply(fn, *args, **kwargs)
 
 
 class MLPMaskDecoder(nn.Module):
@@ -233,6 +329,8 @@ class RegionwiseSideAdapterNetwork(nn.Module):
         x = torch.cat([self.query_embed.expand(x.shape[0], -1, -1), x], dim=1)  # B, Q+L, C
         x = vit.norm_pre(x + pos_embed)
         x = self.fuse(0, x, clip_features, (h, w))
+        if vit.native_ok(x):
+            return self._native_blocks(x, pos_embed, clip_features, (h, w), L)
         outs, san_feats = [], []
         n_blocks = len(vit.blocks)
         for i, blk in enumerate(vit.blocks, start=1):
@@ -243,6 +341,36 @@ class RegionwiseSideAdapterNetwork(nn.Module):
             san_feats.append(grid.contiguous())
             if i < n_blocks:
                 x = x + pos_embed
+        return outs, san_feats
+
+    def _native_blocks(self, x, pos_embed, clip_features, hw, L):
+        """The block loop of ``forward_features`` on the MFMA kernels: the tokens live
+        in ONE padded fp32 stream [B*T, ceil64(width)] that the blocks update in place;
+        the CLIP fusion and the position embedding are added onto its real columns."""
+        vit = self.vit_model
+        B, T, d = x.shape
+        h, w = hw
+        blocks = vit.packed_blocks(x.device)
+        dp = blocks[0].dp
+        s = torch.zeros((B * T, dp), dtype=torch.float32, device=x.device)
+        xs = s.view(B, T, dp)[..., :d]          # the real columns, a view of the stream
+        xs.copy_(x)
+        outs, san_feats = [], []
+        n_blocks = len(blocks)
+        for i, blk in enumerate(blocks, start=1):
+            blk.forward_(s, B, T)
+            if i in self.fusion_map:            # AddFusion onto the patch tokens, in place
+                layer = self.fusion_layers['layer_%d' % i]
+                y = F.interpolate(layer.input_proj(clip_features[self.fusion_map[i]].contiguous()),
+                                  size=(h, w), mode='bilinear', align_corners=False)
+                xs[:, -L:] += y.permute(0, 2, 3, 1).reshape(B, L, d)
+            # (reshape alone would be a VIEW of the stream the next block overwrites)
+            grid = xs[:, -L:].permute(0, 2, 1).reshape(B, d, h, w).contiguous()
+            if i in self.deep_supervision_idxs:
+                outs.append({'query': xs[:, :-L].clone(), 'x': grid})
+            san_feats.append(grid)
+            if i < n_blocks:
+                xs += pos_embed
         return outs, san_feats
 
     def fuse(self, block_idx, x, clip_features, spatial_shape):

@@ -402,12 +402,17 @@ class VeonOccupancyPath(nn.Module):
             xx = layer_3d(xx)
         return self._classify(dec.occupancy_pred(xx), dec.feat_pred(xx))
 
-    def forward(self, images, img_metas, prev_volumes=None, depth=None):
+    def forward(self, images, img_metas, prev_volumes=None, depth=None, with_2d=False):
         """images (B, N, 3, H, W); img_metas = (sensor2egos, ego2globals, intrins,
         post_rots, post_trans, bda) as the reference's ``img[1:7]``;
         ``prev_volumes``: aligned lifted volumes of the past frames, newest first
         (the reference's ``occ_feat_prevs``).  Returns ``bin_occ`` / ``sem_occ`` at
-        ``occ_size`` and ``occ_pred_cls``."""
+        ``occ_size`` and ``occ_pred_cls``.  ``with_2d`` (needs ``side_adapter=True``):
+        also the 2-D mask branch the reference always runs beside the 3-D one
+        (san_in_veon_temporal.py:123-139), on the SAME CLIP features; its outputs come
+        back under ``2d_*`` keys."""
+        if with_2d and self.side_adapter_network is None:
+            raise RuntimeError('VeonOccupancyPath was built without side_adapter=True')
         B, N = images.shape[:2]
         hf, wf = self.input_size[0] // 16, self.input_size[1] // 16
         sem_embed_ds = images.new_zeros((B * N, 1, hf, wf))   # shape carrier only
@@ -422,10 +427,21 @@ class VeonOccupancyPath(nn.Module):
                                    images.device)
             x = dec.fuse(0, None, feats, [supp], depth2, metas2, None, (hf, wf),
                          out_volume=vol, fused=fused)
-            return self._tail(x, prev_volumes)
+            out = self._tail(x, prev_volumes)
+            return self._add_2d(out, images, feats) if with_2d else out
         feats, supp, depth = self._branches(images, depth)
         out = dec(sem_embed_ds, feats, [supp], depth, metas, prev_volumes)
-        return self._classify(out['bin_occ'], out['feat_occ'])
+        out = self._classify(out['bin_occ'], out['feat_occ'])
+        return self._add_2d(out, images, feats) if with_2d else out
+
+    def _add_2d(self, out, images, feats):
+        from .semantic_net.side_adapter import semantic_branch_2d
+        two_d = semantic_branch_2d(self.side_adapter_network, self.clip_rec_head,
+                                   self.ov_classifier_weight, images.flatten(0, 1), feats)
+        out = dict(out)
+        for k in ('mask_preds', 'mask_logits', 'sem_seg_ds', 'sem_embed_ds', 'sem_seg'):
+            out['2d_' + k] = two_d[k]
+        return out
 
 
 class CameraShardedStep:

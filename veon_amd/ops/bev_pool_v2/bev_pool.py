@@ -240,7 +240,11 @@ def rows_forward(depth, feat, ranks_depth, ranks_feat, vstart, bev_feat_shape,
 
 
 _COLD_ORDERS = {}
-COLD_ORDER = os.environ.get('VEON_COLD_ORDER', 'azimuth')   # tools: 'none' = built-in order
+# 'azimuth' = cold_chunk_order(); default: the kernel's built-in order (measured on
+# MI355X at the VEON shape: the azimuth order changes neither the L2 hit rate -- 60 % --
+# nor FETCH_SIZE -- 82 vs 88 MB -- because a chunk of 32 consecutive x spans 25 m of the
+# grid and so most azimuths; its imbalance between the XCDs then costs 10-20 %)
+COLD_ORDER = os.environ.get('VEON_COLD_ORDER', 'none')
 
 
 def cold_chunk_order(B, Zo, Yo, Xo, device, sectors=4, origin=None):
@@ -289,24 +293,12 @@ def cold_chunk_order(B, Zo, Yo, Xo, device, sectors=4, origin=None):
     return tab
 
 
-_SIDE_STREAMS = {}
-SPLIT_LAUNCH = os.environ.get('VEON_POOL_SPLIT', '1') != '0'
-
-
-def _side_stream(dev):
-    s = _SIDE_STREAMS.get(dev)
-    if s is None:
-        s = _SIDE_STREAMS[dev] = torch.cuda.Stream(dev)
-    return s
-
-
 def rows_maxpool(depth, feat, ranks_depth, ranks_feat, vstart, bev_feat_shape, ds,
-                 out_volume=None, chunk_order='default', split=None):
+                 out_volume=None, chunk_order='default'):
     """Pool + (2,2,2) block max by the row kernel: (B,C,Z/2,Y/2,X/2) fp32, or the
     Conv3d body's padded bf16 input when ``out_volume`` is given.  ``chunk_order``:
     an int32 permutation of the cold chunks, None for the kernel's built-in order,
-    'default' = ``cold_chunk_order`` (azimuth sectors per XCD).  ``split`` (default
-    on): the long lists and the short lists as two launches on two streams."""
+    'default' = the module's ``COLD_ORDER`` policy."""
     B, Z, Y, X, C = [int(s) for s in bev_feat_shape]
     dz, dy, dx = [int(v) for v in ds]
     dev = _lib.require_device(depth, feat, ranks_depth, ranks_feat, vstart)
@@ -331,24 +323,13 @@ def rows_maxpool(depth, feat, ranks_depth, ranks_feat, vstart, bev_feat_shape, d
                 or chunk_order.device != dev or not chunk_order.is_contiguous()):
             raise _lib.VeonHipError('chunk_order must be a contiguous int32 permutation '
                                     'of %d chunks on %s' % (want, dev))
-    def launch(part):
-        with _lib.on_device(dev):
-            st = _lib.lib().veon_bev_pool_v2_fwd_rows_maxpool_part(
-                C, B, Z, Y, X, dz, dy, dx, _lib.ptr(depth), _lib.ptr(feat),
-                _feat_code(feat), _lib.ptr(ranks_depth), _lib.ptr(ranks_feat),
-                _lib.ptr(vstart), _lib.ptr(target), padded, feat.numel(),
-                _lib.ptr(chunk_order), part, _lib.stream_ptr(dev))
-        _lib.check(st, 'veon_bev_pool_v2_fwd_rows_maxpool_part')
-    if SPLIT_LAUNCH if split is None else split:
-        # long lists on a forked stream beside the short-list launch (disjoint outputs)
-        cur, side = torch.cuda.current_stream(dev), _side_stream(dev)
-        side.wait_stream(cur)
-        with torch.cuda.stream(side):
-            launch(2)
-        launch(1)
-        cur.wait_stream(side)
-    else:
-        launch(0)
+    with _lib.on_device(dev):
+        st = _lib.lib().veon_bev_pool_v2_fwd_rows_maxpool_ordered(
+            C, B, Z, Y, X, dz, dy, dx, _lib.ptr(depth), _lib.ptr(feat),
+            _feat_code(feat), _lib.ptr(ranks_depth), _lib.ptr(ranks_feat),
+            _lib.ptr(vstart), _lib.ptr(target), padded, feat.numel(),
+            _lib.ptr(chunk_order), _lib.stream_ptr(dev))
+    _lib.check(st, 'veon_bev_pool_v2_fwd_rows_maxpool_ordered')
     return ret
 
 

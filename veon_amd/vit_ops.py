@@ -65,6 +65,22 @@ def layernorm(x, weight, bias, eps=1e-6, out=None):
     return out
 
 
+def layernorm_padded(x, weight, bias, d, eps=1e-6):
+    """x fp32 [T, ld] whose first ``d`` columns are the token -> bf16 [T, ld]:
+    nn.LayerNorm over those d columns, zeros in the padding."""
+    dev = _dev(x, weight, bias)
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 2
+    T, ld = x.shape
+    assert weight.numel() >= d and bias.numel() >= d and d <= ld
+    out = torch.empty((T, ld), dtype=_half.dtype(), device=dev)
+    with _lib.on_device(dev):
+        st = _lib.lib().veon_vit_layernorm_padded(
+            _lib.ptr(x), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(out), T, int(d), ld,
+            float(eps), _lib.stream_ptr(dev))
+    _lib.check(st, 'veon_vit_layernorm_padded')
+    return out
+
+
 def layernorm_f32(x, weight, bias, eps=1e-5):
     """x fp32 [..., d] -> fp32 [..., d] (nn.LayerNorm over the last dim);
     d % 128 == 0, d <= 1024."""
