@@ -372,7 +372,7 @@ def test_align_net_decoder_against_reference_vectors():
         ran = {k for k, v in _lib.CALLS.items() if v > before.get(k, 0)}
         assert {'veon_conv3d_k3_bf16', 'veon_vit_gemm'} <= ran, ran
         assert {'veon_bev_pool_v2_fwd_maxpool_padded',
-                'veon_bev_pool_v2_fwd_rows_maxpool'} & ran, ran
+                'veon_bev_pool_v2_fwd_rows_maxpool_ordered'} & ran, ran
         net.use_hip = False
         for m in (net.occupancy_pred, net.feat_pred):
             m._hip_ok = lambda x: False
@@ -428,9 +428,9 @@ def test_veon_occupancy_path_harness_runs_and_is_stream_invariant():
         b = net(images, geom)
     ran = {k for k, v in _lib.CALLS.items() if v > before.get(k, 0)}
     assert {'veon_vit_block', 'veon_conv2d_k3_bf16', 'veon_conv3d_k3_bf16',
-            'veon_two_hot_depth'} <= ran, ran
+            'veon_two_hot_window'} <= ran, ran
     assert {'veon_bev_pool_v2_fwd_maxpool_padded',
-            'veon_bev_pool_v2_fwd_rows_maxpool'} & ran, ran
+            'veon_bev_pool_v2_fwd_rows_maxpool_ordered'} & ran, ran
     assert a['sem_occ'].shape == (1, 17, 4, 20, 20) and a['bin_occ'].shape == (1, 2, 4, 20, 20)
     assert a['occ_pred_cls'].shape == (1, 20, 20, 4)
     for k in ('sem_occ', 'bin_occ'):

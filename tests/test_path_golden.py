@@ -77,9 +77,11 @@ def test_path_wiring_matches_reference_chain_on_cpu():
 @pytest.mark.gpu
 def test_native_path_logits_match_reference_chain():
     """Voxel logits of the native path (bf16 operands on MFMA, fp32 accumulation, HIP
-    lift with the fused max-pool) against the reference chain's fp32 logits:
-    relative L2 <= 4e-2 and max |diff| <= 8e-2 of the logit range -- the stated bf16
-    tolerance of BASELINE.json's "voxel logits matching the reference"."""
+    lift with the fused max-pool) against the reference chain's fp32 logits.  Measured
+    on MI355X: relative L2 3.9e-3 (sem) / 2.0e-3 (bin), max |diff| 3.2e-3 / 2.7e-3 of
+    the logit range; the bound is that + 50 %: 6e-3 / 5e-3 (round 2 stated 4e-2 / 8e-2
+    without having measured).  The production-width vector with the depth encoder in
+    the loop (tests/test_path_prod_golden.py) is where bf16 costs 2e-2."""
     g = load_golden('path_tiny')
     dev = 'cuda:0'
     net = _build(g, dev, native=True)
@@ -91,8 +93,9 @@ def test_native_path_logits_match_reference_chain():
         got = out[k].float()
         rel = ((got - ref).norm() / ref.norm()).item()
         mx = ((got - ref).abs().max() / (ref.max() - ref.min())).item()
-        assert rel <= 4e-2 and mx <= 8e-2, (k, rel, mx)
+        print('bf16 path_tiny %s: rel L2 %.3e, max/range %.3e' % (k, rel, mx))
+        assert rel <= 6e-3 and mx <= 5e-3, (k, rel, mx)
     # arg-max classes agree on all but a few near-tie voxels
     ref_cls = torch.from_numpy(g['sem_occ']).to(dev).argmax(1)
     agree = (out['sem_occ'].argmax(1) == ref_cls).float().mean().item()
-    assert agree >= 0.97, agree
+    assert agree >= 0.99, agree

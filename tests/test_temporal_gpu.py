@@ -198,7 +198,7 @@ def test_temporal_decoder_fast_path_agrees_with_modules():
                 'veon_conv3d_k3_bf16'} <= ran, ran
         # the fused pool + max-pool: row kernel from 64 channels on, slab kernel below
         assert {'veon_bev_pool_v2_fwd_maxpool_padded',
-                'veon_bev_pool_v2_fwd_rows_maxpool'} & ran, ran
+                'veon_bev_pool_v2_fwd_rows_maxpool_ordered'} & ran, ran
         net.use_hip = False
         for m in (net.occupancy_pred, net.feat_pred):
             m._hip_ok = lambda x: False
