@@ -48,6 +48,34 @@ def test_gemm_bias_bf16(M, N, K):
                                rtol=2 ** -8, atol=2e-3)
 
 
+@pytest.mark.parametrize('cfg', [1, 2, 5, 7, 11, 12, 13, 14])
+@pytest.mark.parametrize('M,N,K', [(5406, 2304, 768), (300, 1024, 4096), (901, 768, 192),
+                                   (257, 520, 64), (1, 4, 64)])
+def test_gemm_every_big_tile_configuration(cfg, M, N, K):
+    """The DMA-ring kernels (1..7: whole K = 64 stages; 11..14: ring of K = 32 granules,
+    four slots, three in flight) forced through veon_gemm_ring_set, on ragged shapes
+    (M, N not multiples of the tile, K of one to 64 stages): all three epilogue
+    families against fp32 references."""
+    from veon_amd import _lib
+    a = _rand(M, K, seed=21).to(torch.bfloat16)
+    w = (_rand(N, K, seed=22) * K ** -0.5).to(torch.bfloat16)
+    bias = _rand(N, seed=23)
+    gamma = _rand(N, seed=24) * 0.1
+    x = _rand(M, N, seed=25)
+    pre = a.float() @ w.float().t() + bias
+    L = _lib.lib()
+    L.veon_gemm_ring_set(cfg)
+    try:
+        got = vit_ops.linear(a, w, bias).float()
+        gelu = vit_ops.linear(a, w, bias, vit_ops.EPI_GELU).float()
+        res = vit_ops.linear_residual_(x.clone(), a, w, bias, gamma)
+    finally:
+        L.veon_gemm_ring_set(-1)
+    torch.testing.assert_close(got, pre, rtol=2 ** -8, atol=2e-3)
+    torch.testing.assert_close(gelu, torch.nn.functional.gelu(pre), rtol=2 ** -8, atol=2e-3)
+    torch.testing.assert_close(res, x + gamma * pre, rtol=1e-4, atol=1e-4)
+
+
 def test_gemm_gelu_and_quickgelu():
     M, N, K = 901, 3072, 768
     a = _rand(M, K, seed=8).to(torch.bfloat16)

@@ -26,8 +26,11 @@ if os.environ.get('SPLITK_EMU'):   # split-K emulated as more rows with a shorte
               ('B fc2 /2', 10812, 768, 1536), ('B fc2 /3', 16218, 768, 1024),
               ('L qkv /2', 10812, 3072, 512), ('B qkv /2', 10812, 2304, 384)]
 NAMES = {0: 'small', 1: '256x256', 2: '192x192', 3: '128x192', 4: '128x256', 5: '256x192',
-         6: '128x128', 7: '256x128'}
-NC = len(NAMES)
+         6: '128x128', 7: '256x128', 11: 'g256x256', 12: 'g256x128', 13: 'g128x256',
+         14: 'g128x128'}
+if os.environ.get('GEMM_CFGS'):
+    NAMES = {int(c): NAMES[int(c)] for c in os.environ['GEMM_CFGS'].split(',')}
+CFGS = sorted(NAMES)
 
 
 def timeit(fn, iters=20):
@@ -56,7 +59,7 @@ def main():
         ref = a.float() @ w.float().t() + b
         flops = 2.0 * M * N * K
         res = {}
-        for cfg in range(NC):
+        for cfg in CFGS:
             L.veon_gemm_ring_set(cfg)
             out = vit_ops.linear(a, w, b)
             torch.cuda.synchronize()
@@ -64,7 +67,7 @@ def main():
             res[cfg] = [err]
         auto = None
         for _ in range(rounds):
-            for cfg in range(NC):
+            for cfg in CFGS:
                 L.veon_gemm_ring_set(cfg)
                 res[cfg].append(timeit(lambda: vit_ops.linear(a, w, b)))
             L.veon_gemm_ring_set(-1)
@@ -74,11 +77,11 @@ def main():
                 timeit(lambda: torch.nn.functional.linear(a, w, b.bfloat16())))
         L.veon_gemm_ring_set(-1)
         line = '%-10s %5dx%4dx%4d |' % (name, M, N, K)
-        for cfg in range(NC):
+        for cfg in CFGS:
             t = min(res[cfg][1:])
             line += ' %s %6.1f%s' % (NAMES[cfg], t, '!' if res[cfg][0] > 1e-2 else '')
         tt = min(res['torch'][1:])
-        best = min(range(NC), key=lambda c: min(res[c][1:]))
+        best = min(CFGS, key=lambda c: min(res[c][1:]))
         line += ' | auto %6.1f | torch %6.1f | best %s %.0f TF/s' % (
             auto, tt, NAMES[best], flops / min(res[best][1:]) / 1e6)
         print(line, flush=True)

@@ -606,6 +606,151 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_ring(
   }
 }
 
+// --------------------------------------- GEMM, big tiles + ring of K = 32 granules
+// k_gemm_ring holds S = 2 whole K-steps (64 deep) of a 256 x 256 tile in LDS, so only ONE
+// step is in flight while the other is consumed: every step pays the L2 latency of its
+// refill (measured 2.0 us per step against 0.85 us of MFMA work).  Here the same tile is
+// streamed in granules of K = 32 (one MFMA depth): 32 KB per granule, FOUR slots, THREE
+// granules in flight (counted vmcnt, raw barrier: LDS-DMA stays in flight across it),
+// i.e. 1.3 us of matrix work between the issue of a granule and its use.  The LDS image
+// of a granule is [rows][32] (64-byte rows); a DMA piece is 16 rows; the 16-byte chunk
+// of a row is XOR-ed with a key of the row so that every ds_read_b128 lane group (four
+// NON-contiguous groups of 16 lanes: {0-3,12-15,20-27}, ...) touches 16 different
+// 16-byte slots of the 256-byte bank row:
+//   token rows (16 consecutive rows per fragment):         key = (-(row >> 2)) & 3
+//   weight rows (paired tiles: rows {0-3, 8-11, 16-19, 24-27} + 4 t): key = (-(row >> 3)) & 3
+// (derivation in DESIGN 4b).  Same fragment maps, epilogues and tile order as k_gemm_ring.
+constexpr int GK = 32;   // granule depth
+__device__ __forceinline__ int gkey_a(int row) { return (-(row >> 2)) & 3; }
+__device__ __forceinline__ int gkey_w(int row) { return (-(row >> 3)) & 3; }
+
+template <int EPI, int WM, int WN, int MT, int NT>
+__global__ __launch_bounds__(64 * WM * WN) void k_gemm_g32(
+    const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
+    const float* __restrict__ bias, const float* __restrict__ gamma,
+    float* __restrict__ resid, bf16_t* __restrict__ out, int M, int N, int K,
+    int grid_n) {
+  constexpr int NW = WM * WN, SLOTS = 4, AHEAD = SLOTS - 1;
+  constexpr int BM = WM * 16 * MT, TBN = WN * 16 * NT;
+  static_assert(NT % 2 == 0, "paired weight tiles (16-byte epilogues, the weight key)");
+  constexpr int A_ELEMS = BM * GK, SLOT_ELEMS = (BM + TBN) * GK;
+  constexpr int PIECES = (BM + TBN) / 16;  // 1 KiB DMA pieces (16 rows) per granule
+  static_assert(PIECES % NW == 0, "every wave issues the same number of pieces");
+  constexpr int P = PIECES / NW;
+  static_assert(P * AHEAD < 64, "vmcnt range");
+  static_assert(SLOTS * SLOT_ELEMS * 2 <= 160 * 1024, "LDS");
+  extern __shared__ __attribute__((aligned(16))) bf16_t smem[];  // [SLOTS][A | W]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int nwg = gridDim.x;
+  const int q8 = nwg / 8, r8 = nwg % 8, xcd = blockIdx.x % 8;
+  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) +
+                 blockIdx.x / 8;
+  const int m0 = (wg / grid_n) * BM, n0 = (wg % grid_n) * TBN;
+  const int fr = lane & 15, fg = lane >> 4;
+
+  // DMA map: piece p = wave + j*NW covers rows 16p .. 16p+15 of the granule image;
+  // lane l lands in row 16p + l/4, physical chunk l%4 = logical chunk (l%4) ^ key(row)
+  const rsrc_t rsA = make_rsrc(A), rsW = make_rsrc(W);
+  int src[P];
+#pragma unroll
+  for (int j = 0; j < P; ++j) {
+    const int r = (wave + j * NW) * 16 + (lane >> 2);
+    if (r < BM) {
+      const int c = (lane & 3) ^ gkey_a(r);
+      const int gm = m0 + r < M ? m0 + r : M - 1;
+      src[j] = 2 * (gm * K + c * 8);
+    } else {
+      const int c = (lane & 3) ^ gkey_w(r - BM);
+      const int gn = n0 + (r - BM) < N ? n0 + (r - BM) : N - 1;
+      src[j] = 2 * (gn * K + c * 8);
+    }
+  }
+  auto piece = [&](int j, bf16_t* d, int k0) {
+    if ((wave + j * NW) * 16 < BM)   // a piece is token rows or weight rows, wave-uniform
+      buffer_load_lds16(rsA, (lptr_t)(d + (wave + j * NW) * 512), src[j], 2 * k0);
+    else
+      buffer_load_lds16(rsW, (lptr_t)(d + (wave + j * NW) * 512), src[j], 2 * k0);
+  };
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // fragment addresses (elements inside a slot): token row ra0 + 16 i shares its key
+  // bits with ra0 only through (row >> 2) & 3, which 16 i does not change
+  const int ra0 = wm * (16 * MT) + fr;
+  const int baseA = ra0 * GK + ((fg ^ gkey_a(ra0)) * 8);
+  int offW[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i) {
+    const int rw = wn * (16 * NT) + weight_row<NT>(i, fr);
+    offW[i] = A_ELEMS + rw * GK + ((fg ^ gkey_w(rw)) * 8);
+  }
+
+  const int ng = K / GK;
+#pragma unroll
+  for (int t = 0; t < AHEAD; ++t)
+    if (t < ng) {
+      bf16_t* d = smem + t * SLOT_ELEMS;
+#pragma unroll
+      for (int j = 0; j < P; ++j) piece(j, d, t * GK);
+    }
+  constexpr int MFMAS = MT * NT;
+  static_assert(MFMAS >= P, "at least one MFMA per DMA piece");
+  constexpr int MPP = MFMAS / P;
+  constexpr int kPD = 2, RS = kPD + 1;
+  for (int kt = 0; kt < ng; ++kt) {
+    // granule kt has landed when at most min(AHEAD - 1, ng - 1 - kt) younger ones are
+    // outstanding
+    const int younger = ng - 1 - kt;
+    if (younger >= AHEAD - 1) wait_vmcnt<P * (AHEAD - 1)>();
+    else if (younger == 1) wait_vmcnt<P>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();  // everyone's pieces landed; slot of kt-1 is free
+    const bool refill = kt + AHEAD < ng;
+    bf16_t* rd = smem + ((kt + AHEAD) % SLOTS) * SLOT_ELEMS;
+    const int rk0 = (kt + AHEAD) * GK;
+    const bf16_t* st = smem + (kt % SLOTS) * SLOT_ELEMS;
+    bf16x8 fw[NT], fa[RS];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) fw[j] = *reinterpret_cast<const bf16x8*>(st + offW[j]);
+#pragma unroll
+    for (int q = 0; q < kPD; ++q)
+      fa[q] = *reinterpret_cast<const bf16x8*>(st + baseA + q * 16 * GK);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      if (i + kPD < MT)
+        fa[(i + kPD) % RS] =
+            *reinterpret_cast<const bf16x8*>(st + baseA + (i + kPD) * 16 * GK);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        acc[i][j] = mfma_16x16x32(fw[j], fa[i % RS], acc[i][j]);
+        const int c = i * NT + j;  // compile-time after unrolling
+        if (c % MPP == MPP - 1 && c / MPP < P) {
+          if (refill) piece(c / MPP, rd, rk0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int m = m0 + wm * (16 * MT) + i * 16 + fr;
+    if (m >= M) continue;
+#pragma unroll
+    for (int p2 = 0; p2 < NT / 2; ++p2) {
+      const int n = n0 + wn * (16 * NT) + p2 * 32 + fg * 8;
+      if (n >= N) continue;
+      gemm_epilogue_store8<EPI>(acc[i][2 * p2], acc[i][2 * p2 + 1], m, n, N, bias, gamma,
+                                resid, out);
+    }
+  }
+}
+
 // ------------------------------------------------------------------ attention
 // qkv: [B, T, 3, H, 64] bf16 (the packed output of the qkv projection, q already
 // scaled by head_dim^-0.5 through the weights).  out: [B, T, H*64] bf16.
@@ -1110,6 +1255,42 @@ int veon_vit_gemm(const void* a_bf16, const void* w_bf16, const float* bias,
     if (epilogue == EPI_AFFINE_SIGM) sel = 0;   // small-tile kernel only
     // the ring kernel addresses both matrices with 32-bit byte offsets
     if ((int64_t)M * K * 2 >= (1ll << 31) || (int64_t)N * K * 2 >= (1ll << 31)) sel = 0;
+    if (sel >= 11 && K % GK == 0) {
+#define VEON_G32(EPI, WM, WN, MT, NT)                                                  \
+  do {                                                                                \
+    constexpr int bm_ = WM * 16 * MT, bn_ = WN * 16 * NT;                             \
+    constexpr int lds = 4 * (bm_ + bn_) * GK * (int)sizeof(bf16_t);                   \
+    static const hipError_t attr = hipFuncSetAttribute(                               \
+        reinterpret_cast<const void*>(&k_gemm_g32<EPI, WM, WN, MT, NT>),              \
+        hipFuncAttributeMaxDynamicSharedMemorySize, lds);                             \
+    if (attr != hipSuccess) return VEON_ERR_LAUNCH;                                   \
+    const int gn = (N + bn_ - 1) / bn_, gm = (M + bm_ - 1) / bm_;                     \
+    hipLaunchKernelGGL((k_gemm_g32<EPI, WM, WN, MT, NT>), dim3((unsigned)(gn * gm)),  \
+                       dim3(64 * WM * WN), lds, s, A, W, bias, gamma, resid, O, M, N, \
+                       K, gn);                                                        \
+  } while (0)
+#define VEON_G32_SEL(EPI)                                            \
+  do {                                                               \
+    switch (sel) {                                                   \
+      case 11: VEON_G32(EPI, 2, 4, 8, 4); break; /* 256 x 256 */     \
+      case 12: VEON_G32(EPI, 4, 2, 4, 4); break; /* 256 x 128 */     \
+      case 13: VEON_G32(EPI, 2, 4, 4, 4); break; /* 128 x 256 */     \
+      default: VEON_G32(EPI, 2, 4, 4, 2); break; /* 128 x 128 */     \
+    }                                                                \
+  } while (0)
+      switch (epilogue) {
+        case EPI_BF16: VEON_G32_SEL(EPI_BF16); break;
+        case EPI_GELU: VEON_G32_SEL(EPI_GELU); break;
+        case EPI_QUICKGELU: VEON_G32_SEL(EPI_QUICKGELU); break;
+        case EPI_RESID: VEON_G32_SEL(EPI_RESID); break;
+        case EPI_AFFINE: VEON_G32_SEL(EPI_AFFINE); break;
+        case EPI_AFFINE_RELU: VEON_G32_SEL(EPI_AFFINE_RELU); break;
+        default: return VEON_ERR_BAD_ARG;
+      }
+#undef VEON_G32_SEL
+#undef VEON_G32
+      return launch_status();
+    }
     if (sel > 0) {
 #define VEON_RING(EPI, WM, WN, MT, NT, S)                                             \
   do {                                                                                \
