@@ -329,6 +329,14 @@ int64_t veon_lss_prepare_workspace_bytes(int64_t num_points,
  *     call leaves the histogram zeroed again, so no memset node is needed.
  *     With 0 the histogram is cleared first (hipMemsetAsync).
  */
+/*
+ * AlignNetOcc3D.prepare_meta (align_net_occ3d.py:328-352) for one frame: out[b,n] =
+ * inverse(ego2global[b,0]) @ ego2global[b,n] @ sensor2ego[b,n], (B,N,4,4) fp32 in and
+ * out, the algebra in double precision (the reference casts to double, too).
+ */
+int veon_sensor2keyego(int B, int N, const float *sensor2ego, const float *ego2global,
+                       float *out, void *stream);
+
 int veon_lss_prepare_cameras(int B, int N, int D, int H, int W, const float *xs,
                              const float *ys, const float *ds,
                              const float *sensor2ego, const float *cam2imgs,
@@ -523,6 +531,21 @@ typedef struct veon_vit_block_weights {
   float ln1_eps, ln2_eps;
   int mlp_dim, act;
 } veon_vit_block_weights;
+/*
+ * Split-K form of the residual GEMM (resid += gamma * (a @ w^T + bias)) for fc2-shaped
+ * problems (long K, few output columns: M = 5406, N = 768 / 1024, K = 3072 / 4096): two
+ * workgroups per output tile take half of K each, the first to finish parks its fp32
+ * accumulators in `slab`, the second adds them to its own and runs the epilogue
+ * (deterministic: a + b is commutative).  veon_vit_gemm_splitk_plan -> slab bytes needed
+ * (0: the shape is not split).  sync_words (2 ints per tile): ZERO on entry, left zero.
+ * veon_vit_block uses it for fc2 with its (by then free) qkv buffer as the slab; the
+ * block workspace therefore has to be ZERO when first used (it ends in the sync words).
+ */
+int64_t veon_vit_gemm_splitk_plan(int M, int N, int K, int *tile_out);
+int veon_vit_gemm_splitk(const void *a_bf16, const void *w_bf16, const float *bias,
+                         const float *gamma, float *resid, int M, int N, int K,
+                         void *slab, int64_t slab_bytes, int *sync_words,
+                         int64_t sync_ints, void *stream);
 int64_t veon_vit_block_workspace_bytes(int B, int T, int d, int mlp_dim);
 int veon_vit_block(float *x, const veon_vit_block_weights *w,
                    const float *attn_bias, int64_t bias_batch_stride,

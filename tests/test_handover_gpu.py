@@ -90,3 +90,39 @@ def test_volume_maxpool2_equals_torch_amax():
     # odd extents are refused
     assert _lib.lib().veon_volume_maxpool2_f32(_lib.ptr(vol), _lib.ptr(out), 1, 3, 4, 4,
                                                ctypes.c_void_p(0)) != 0
+
+
+def test_sensor2keyego_kernel_equals_the_reference_algebra():
+    """AlignNetOcc3D.prepare_meta's 4x4 algebra (align_net_occ3d.py:328-352) in one
+    launch: inverse(ego2global[:, 0]) @ ego2global @ sensor2ego in double precision,
+    against torch's own double-precision inverse / matmul of the same inputs."""
+    import torch
+    from veon_amd import lss_prepare_hip, synthetic
+    rig = synthetic.make_rig(2, 6, (256, 704))
+    s2e = rig['sensor2ego'].to('cuda:0')
+    g = torch.Generator().manual_seed(3)
+    # general rigid ego poses (yaw + translation per camera time stamp), not identity
+    e2g = torch.eye(4).repeat(2, 6, 1, 1)
+    ang = torch.rand(2, 6, generator=g) * 6.28
+    e2g[..., 0, 0], e2g[..., 0, 1] = ang.cos(), -ang.sin()
+    e2g[..., 1, 0], e2g[..., 1, 1] = ang.sin(), ang.cos()
+    e2g[..., :3, 3] = torch.randn(2, 6, 3, generator=g) * 50
+    e2g = e2g.to('cuda:0')
+    got = lss_prepare_hip.sensor2keyego(s2e, e2g)
+    key = e2g[:, :1].double()
+    want = (torch.linalg.inv(key) @ e2g.double() @ s2e.double()).float()
+    torch.testing.assert_close(got, want, rtol=1e-6, atol=1e-5)
+    # and through the decoder's prepare_meta (one frame, inference)
+    from veon_amd.models.semantic_net import AlignNetOcc3D
+    dec = AlignNetOcc3D(clip_dim=32, hsa_dim=16, embed_dim=64, clip_outdim=24,
+                        layer_lifting_map=['2->0->0'], fusion_type='cat_fusion', layer_depth=2)
+    dec.num_frame, dec.num_camera = 1, 6
+    metas = [s2e, e2g, rig['intrins'].to('cuda:0'), rig['post_rots'].to('cuda:0'),
+             rig['post_trans'].to('cuda:0'), rig['bda'].to('cuda:0')[None]]
+    with torch.no_grad():
+        fast = dec.prepare_meta(metas)
+    with torch.enable_grad():          # the torch definition
+        slow = dec.prepare_meta(metas)
+    for a, b in zip(fast, slow):
+        assert a.shape == b.shape
+        torch.testing.assert_close(a, b, rtol=1e-6, atol=1e-5)

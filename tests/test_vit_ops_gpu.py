@@ -76,6 +76,39 @@ def test_gemm_every_big_tile_configuration(cfg, M, N, K):
     torch.testing.assert_close(res, x + gamma * pre, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize('M,N,K', [(5406, 768, 3072), (5406, 1024, 4096), (4200, 768, 2048)])
+def test_gemm_splitk_residual(M, N, K):
+    """fc2-shaped residual GEMM with K split over two workgroups per tile (slab + ticket
+    + agent-scope release / acquire): against the fp32 reference, against the unsplit
+    kernel within accumulation-order noise, bit-identical across repeated launches (the
+    result must not depend on which half arrives first) and with the sync words left
+    zero."""
+    from veon_amd import _lib
+    L = _lib.lib()
+    a = _rand(M, K, seed=31).to(torch.bfloat16)
+    w = (_rand(N, K, seed=32) * K ** -0.5).to(torch.bfloat16)
+    bias = _rand(N, seed=33)
+    gamma = _rand(N, seed=34) * 0.1
+    x = _rand(M, N, seed=35)
+    need = L.veon_vit_gemm_splitk_plan(M, N, K, None)
+    assert need > 0
+    slab = torch.empty(need, dtype=torch.uint8, device=DEV)
+    sync = torch.zeros(1024, dtype=torch.int32, device=DEV)
+    ref = x + gamma * (a.float() @ w.float().t() + bias)
+    outs = []
+    for _ in range(4):
+        slab.fill_(255)     # stale slab contents must not matter
+        outs.append(vit_ops.linear_residual_splitk_(x.clone(), a, w, bias, gamma,
+                                                    (slab, sync)))
+        assert int(sync.abs().sum()) == 0
+    torch.testing.assert_close(outs[0], ref, rtol=1e-4, atol=1e-4)
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+    plain = vit_ops.linear_residual_(x.clone(), a, w, bias, gamma)
+    torch.testing.assert_close(outs[0], plain, rtol=1e-5, atol=2e-5)
+    assert L.veon_vit_gemm_splitk_plan(901, 768, 768, None) == 0      # short K: not split
+
+
 def test_gemm_gelu_and_quickgelu():
     M, N, K = 901, 3072, 768
     a = _rand(M, K, seed=8).to(torch.bfloat16)

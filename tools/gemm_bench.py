@@ -76,6 +76,17 @@ def main():
             res.setdefault('torch', [0.0]).append(
                 timeit(lambda: torch.nn.functional.linear(a, w, b.bfloat16())))
         L.veon_gemm_ring_set(-1)
+        sk = ''
+        if L.veon_vit_gemm_splitk_plan(M, N, K, None) > 0:   # the residual form, split-K
+            xr = torch.randn(M, N, device=dev, generator=g)
+            need = L.veon_vit_gemm_splitk_plan(M, N, K, None)
+            wsk = (torch.empty(need, dtype=torch.uint8, device=dev),
+                   torch.zeros(1024, dtype=torch.int32, device=dev))
+            t_sk = min(timeit(lambda: vit_ops.linear_residual_splitk_(xr, a, w, b, None, wsk))
+                       for _ in range(rounds))
+            t_pl = min(timeit(lambda: vit_ops.linear_residual_(xr, a, w, b, None))
+                       for _ in range(rounds))
+            sk = ' | resid: split-K %6.1f plain %6.1f' % (t_sk, t_pl)
         line = '%-10s %5dx%4dx%4d |' % (name, M, N, K)
         for cfg in CFGS:
             t = min(res[cfg][1:])
@@ -83,7 +94,7 @@ def main():
         tt = min(res['torch'][1:])
         best = min(CFGS, key=lambda c: min(res[c][1:]))
         line += ' | auto %6.1f | torch %6.1f | best %s %.0f TF/s' % (
-            auto, tt, NAMES[best], flops / min(res[best][1:]) / 1e6)
+            auto, tt, NAMES[best], flops / min(res[best][1:]) / 1e6) + sk
         print(line, flush=True)
 
 

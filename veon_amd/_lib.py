@@ -85,6 +85,8 @@ _SIGNATURES = {
     'veon_vit_gemm': (_ci, [_vp] * 6 + [_ci] * 4 + [_vp]),
     'veon_vit_attention': (_ci, [_vp, _vp, _i64, _i64, _vp, _ci, _ci, _ci, _ci, _vp]),
     'veon_vit_block_workspace_bytes': (_i64, [_ci] * 4),
+    'veon_vit_gemm_splitk_plan': (_i64, [_ci, _ci, _ci, _vp]),
+    'veon_vit_gemm_splitk': (_ci, [_vp] * 5 + [_ci] * 3 + [_vp, _i64, _vp, _i64, _vp]),
     'veon_vit_block': (_ci, [_vp, _vp, _vp, _i64, _i64, _vp, _i64] + [_ci] * 4 + [_vp]),
     'veon_conv3d_guard_rows': (_i64, [_ci, _ci]),
     'veon_conv_debug_set': (None, [_ci]),
@@ -112,6 +114,7 @@ _SIGNATURES = {
     'veon_volume_pack_bf16': (_ci, [_vp, _vp] + [_ci] * 5 + [_vp]),
     'veon_volume_unpack_f32': (_ci, [_vp, _vp] + [_ci] * 5 + [_vp]),
     'veon_camera_matrices': (_ci, [_ci] + [_vp] * 6 + [_vp]),
+    'veon_sensor2keyego': (_ci, [_ci, _ci, _vp, _vp, _vp, _vp]),
     'veon_lidar_coor': (_ci, [_ci] * 5 + [_vp] * 9 + [_vp]),
     'veon_lss_prepare_workspace_bytes': (_i64, [_i64, _i64]),
     'veon_lss_prepare_cameras': (_ci, [_ci] * 5 + [_vp] * 8 + [_vp] * 3 + [_i64, _vp, _i64, _ci]

@@ -129,6 +129,72 @@ __global__ __launch_bounds__(kBlock) void k_camera_matrices(
   for (int k = 0; k < 9; ++k) post_rots_inv[i * 9 + k] = pri[k];
 }
 
+// AlignNetOcc3D.prepare_meta (align_net_occ3d.py:328-352): every camera's
+// sensor -> KEY-ego transform, global2keyego @ ego2global @ sensor2ego with
+// global2keyego = inverse(ego2global of the first camera of the first frame), in double
+// precision as the reference computes it, rounded to float once.  One lane per camera:
+// fourteen tiny torch launches (LU factorisation, solves, batched matmuls, copies) in one.
+__device__ __forceinline__ void inv4_f64(const double* m, double* o) {
+  // Gauss-Jordan with partial pivoting on [m | I]
+  double a[4][8];
+  for (int r = 0; r < 4; ++r)
+    for (int c = 0; c < 4; ++c) {
+      a[r][c] = m[r * 4 + c];
+      a[r][4 + c] = r == c ? 1.0 : 0.0;
+    }
+  for (int col = 0; col < 4; ++col) {
+    int piv = col;
+    double best = fabs(a[col][col]);
+    for (int r = col + 1; r < 4; ++r)
+      if (fabs(a[r][col]) > best) {
+        best = fabs(a[r][col]);
+        piv = r;
+      }
+    if (piv != col)
+      for (int c = 0; c < 8; ++c) {
+        const double t = a[col][c];
+        a[col][c] = a[piv][c];
+        a[piv][c] = t;
+      }
+    const double d = 1.0 / a[col][col];
+    for (int c = 0; c < 8; ++c) a[col][c] *= d;
+    for (int r = 0; r < 4; ++r)
+      if (r != col) {
+        const double f = a[r][col];
+        for (int c = 0; c < 8; ++c) a[r][c] -= f * a[col][c];
+      }
+  }
+  for (int r = 0; r < 4; ++r)
+    for (int c = 0; c < 4; ++c) o[r * 4 + c] = a[r][4 + c];
+}
+
+__global__ __launch_bounds__(64) void k_sensor2keyego(
+    int B, int N, const float* __restrict__ sensor2ego, const float* __restrict__ ego2global,
+    float* __restrict__ out) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= B * N) return;
+  const int b = i / N;
+  double key[16], inv[16], e2g[16], s2e[16], t[16];
+  for (int k = 0; k < 16; ++k) {
+    key[k] = ego2global[(int64_t)b * N * 16 + k];   // camera 0 of this sample
+    e2g[k] = ego2global[(int64_t)i * 16 + k];
+    s2e[k] = sensor2ego[(int64_t)i * 16 + k];
+  }
+  inv4_f64(key, inv);
+  for (int r = 0; r < 4; ++r)
+    for (int c = 0; c < 4; ++c) {
+      double acc = 0.0;
+      for (int k = 0; k < 4; ++k) acc += inv[r * 4 + k] * e2g[k * 4 + c];
+      t[r * 4 + c] = acc;
+    }
+  for (int r = 0; r < 4; ++r)
+    for (int c = 0; c < 4; ++c) {
+      double acc = 0.0;
+      for (int k = 0; k < 4; ++k) acc += t[r * 4 + k] * s2e[k * 4 + c];
+      out[(int64_t)i * 16 + r * 4 + c] = (float)acc;
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void k_lidar_coor(
     Geometry g, int N, int D, int H, int W, float* __restrict__ coor) {
   const int bn = blockIdx.y;
@@ -522,6 +588,14 @@ int veon_camera_matrices(int BN, const float* sensor2ego, const float* cam2imgs,
                      dim3(kBlock), 0, static_cast<hipStream_t>(stream), BN,
                      sensor2ego, cam2imgs, post_rots, post_rots_inv, combine,
                      trans);
+  return launch_status();
+}
+
+int veon_sensor2keyego(int B, int N, const float* sensor2ego, const float* ego2global,
+                       float* out, void* stream) {
+  if (B <= 0 || N <= 0 || !sensor2ego || !ego2global || !out) return VEON_ERR_BAD_ARG;
+  hipLaunchKernelGGL(k_sensor2keyego, dim3((unsigned)((B * N + 63) / 64)), dim3(64), 0,
+                     static_cast<hipStream_t>(stream), B, N, sensor2ego, ego2global, out);
   return launch_status();
 }
 

@@ -432,12 +432,21 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int EPI, int WM, int WN, int MT, int NT, int S>
+// SK = 2: split-K.  Workgroups 2t and 2t + 1 (neighbours in the XCD-contiguous order:
+// same XCD, speed only) compute the two K halves of tile t.  Whoever draws ticket 0
+// from sync[2t] stores its accumulators to the tile's fp32 slab (plain 16-byte stores,
+// every wave drains them, barrier, ONE agent-scope release by lane 0, then the flag
+// sync[2t + 1]); whoever draws ticket 1 polls that flag (relaxed), takes ONE agent-scope
+// acquire, adds the slab to its own registers and runs the epilogue, then resets both
+// words.  The first arriver is resident by then, so the wait cannot deadlock; a + b is
+// commutative in fp32, so the result does not depend on who came first.  sync[] must be
+// zero at launch and is left zero.
+template <int EPI, int WM, int WN, int MT, int NT, int S, int SK = 1>
 __global__ __launch_bounds__(64 * WM * WN) void k_gemm_ring(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
     const float* __restrict__ bias, const float* __restrict__ gamma,
     float* __restrict__ resid, bf16_t* __restrict__ out, int M, int N, int K,
-    int grid_n, int abl) {
+    int grid_n, int abl, float* __restrict__ slab = nullptr, int* __restrict__ sync = nullptr) {
   constexpr int NW = WM * WN;
   constexpr int BM = WM * 16 * MT, TBN = WN * 16 * NT;
   constexpr int A_ELEMS = BM * BK, STAGE_ELEMS = (BM + TBN) * BK;
@@ -453,8 +462,10 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_ring(
   // stay in one L2
   const int nwg = gridDim.x;
   const int q8 = nwg / 8, r8 = nwg % 8, xcd = blockIdx.x % 8;
-  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) +
-                 blockIdx.x / 8;
+  const int wgl = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) +
+                  blockIdx.x / 8;
+  const int wg = wgl / SK, slice = wgl % SK;
+  const int kbase = slice * (K / SK);   // this workgroup's K range (SK = 1: all of K)
   const int m0 = (wg / grid_n) * BM, n0 = (wg % grid_n) * TBN;
   const int fr = lane & 15, fg = lane >> 4;
 
@@ -509,11 +520,11 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_ring(
     offW[i] = A_ELEMS + rw * BK + ((fg ^ swz_w(rw)) * 8);
   }
 
-  const int nk = K / BK;
+  const int nk = K / SK / BK;
   // prologue: S - 1 stages in flight (fewer when K is short)
 #pragma unroll
   for (int t = 0; t < S - 1; ++t)
-    if (t < nk) dma(t, t * BK);
+    if (t < nk) dma(t, kbase + t * BK);
   // With S >= 3 the refill of a K-step is not issued as one burst behind the
   // barrier (every wave would sit in the memory pipe's issue queue while the
   // matrix pipe idles) but one piece after every MPP MFMAs: the queued MFMAs
@@ -537,7 +548,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_ring(
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();  // everyone's pieces landed, stage kt-1 is free
     const bool refill = (kt + S - 1 < nk) && !(abl & 2);
-    const int rstage = (kt + S - 1) % S, rk0 = (kt + S - 1) * BK;
+    const int rstage = (kt + S - 1) % S, rk0 = kbase + (kt + S - 1) * BK;
     if (!ILV && refill) dma(rstage, rk0);
     const bf16_t* st = smem + (kt % S) * STAGE_ELEMS;
     bf16_t* rd = smem + rstage * STAGE_ELEMS;
@@ -578,6 +589,59 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_ring(
         }
       }
       __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  if constexpr (SK == 2) {
+    // (the ticket travels through the staging array itself: a second __shared__ object
+    //  beside a DMA target can make hipcc drain vmcnt before every fragment read)
+    int* ticket_s = reinterpret_cast<int*>(smem);
+    __syncthreads();   // every wave is out of the main loop (LDS no longer read)
+    if (tid == 0)
+      *ticket_s = __hip_atomic_fetch_add(&sync[2 * wg], 1, __ATOMIC_RELAXED,
+                                         __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int ticket = *ticket_s;
+    // slab image: accumulator (i, j) of wave w, lane l at float4 index
+    // ((w * MT + i) * NT + j) * 64 + l: every wave instruction moves 1 KiB contiguous
+    float4* sl = reinterpret_cast<float4*>(slab) +
+                 ((int64_t)wg * NW + wave) * (MT * NT * 64) + lane;
+    if (ticket == 0) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          sl[(i * NT + j) * 64] = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2],
+                                              acc[i][j][3]);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(&sync[2 * wg + 1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      return;
+    }
+    if (tid == 0) {
+      while (__hip_atomic_load(&sync[2 * wg + 1], __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT) == 0)
+        __builtin_amdgcn_s_sleep(2);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const float4 p = sl[(i * NT + j) * 64];
+        acc[i][j][0] += p.x;
+        acc[i][j][1] += p.y;
+        acc[i][j][2] += p.z;
+        acc[i][j][3] += p.w;
+      }
+    if (tid == 0) {   // leave the words zero for the next launch
+      __hip_atomic_store(&sync[2 * wg], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&sync[2 * wg + 1], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
   if (abl & 1) {  // ablation: no epilogue stores
@@ -1217,6 +1281,62 @@ int veon_vit_layernorm_padded(const float* x, const float* gamma, const float* b
   return launch_status();
 }
 
+// fc2-shaped GEMMs (residual epilogue, long K, few output columns) leave most CUs idle
+// with big tiles and drown in operand re-reads with small ones: split K in two.
+// slab: tiles x BM x BN fp32 of scratch; sync: 2 ints per tile, ZERO on entry, left zero.
+int64_t veon_vit_gemm_splitk_plan(int M, int N, int K, int* tile_out) {
+  // -> slab bytes (0 = no split-K for this shape); *tile_out 0 = 192 x 192, 1 = 192 x 256
+  if (tile_out) *tile_out = -1;
+  if (K < 2048 || K % (2 * BK) != 0 || M < 1024) return 0;
+  auto wgs = [&](int bm, int bn) {
+    return (int64_t)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
+  };
+  const int64_t a = 2 * wgs(192, 192), b = 2 * wgs(192, 256);
+  const bool oka = a > 160 && a <= kNumCU, okb = b > 160 && b <= kNumCU;
+  if (!oka && !okb) return 0;
+  const bool use_b = okb && (!oka || b > a);
+  if (tile_out) *tile_out = use_b ? 1 : 0;
+  return (use_b ? b / 2 * 192 * 256 : a / 2 * 192 * 192) * 4;
+}
+
+int veon_vit_gemm_splitk(const void* a_bf16, const void* w_bf16, const float* bias,
+                         const float* gamma, float* resid, int M, int N, int K,
+                         void* slab, int64_t slab_bytes, int* sync_words,
+                         int64_t sync_ints, void* stream) {
+  int tile = -1;
+  const int64_t need = veon_vit_gemm_splitk_plan(M, N, K, &tile);
+  if (need == 0 || !a_bf16 || !w_bf16 || !resid || !slab || !sync_words ||
+      slab_bytes < need || N % 4 != 0)
+    return VEON_ERR_BAD_ARG;
+  if (!al16(a_bf16) || !al16(w_bf16) || (bias && !al16(bias)) || (gamma && !al16(gamma)) ||
+      !al16(resid) || !al16(slab))
+    return VEON_ERR_BAD_ARG;
+  if ((int64_t)M * K * 2 >= (1ll << 31) || (int64_t)N * K * 2 >= (1ll << 31))
+    return VEON_ERR_BAD_ARG;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const bf16_t* A = static_cast<const bf16_t*>(a_bf16);
+  const bf16_t* W = static_cast<const bf16_t*>(w_bf16);
+#define VEON_RING_SK(WM, WN, MT, NT, S)                                                 \
+  do {                                                                                 \
+    constexpr int bm_ = WM * 16 * MT, bn_ = WN * 16 * NT;                              \
+    constexpr int lds = S * (bm_ + bn_) * BK * (int)sizeof(bf16_t);                    \
+    static const hipError_t attr = hipFuncSetAttribute(                                \
+        reinterpret_cast<const void*>(&k_gemm_ring<EPI_RESID, WM, WN, MT, NT, S, 2>),  \
+        hipFuncAttributeMaxDynamicSharedMemorySize, lds);                              \
+    if (attr != hipSuccess) return VEON_ERR_LAUNCH;                                    \
+    const int gn = (N + bn_ - 1) / bn_, gm = (M + bm_ - 1) / bm_;                      \
+    if ((int64_t)2 * gn * gm > sync_ints) return VEON_ERR_WORKSPACE;                   \
+    hipLaunchKernelGGL((k_gemm_ring<EPI_RESID, WM, WN, MT, NT, S, 2>),                 \
+                       dim3((unsigned)(2 * gn * gm)), dim3(64 * WM * WN), lds, s, A, W, \
+                       bias, gamma, resid, nullptr, M, N, K, gn, 0,                    \
+                       static_cast<float*>(slab), sync_words);                         \
+  } while (0)
+  if (tile == 1) VEON_RING_SK(2, 4, 6, 4, 2);   /* 192 x 256 */
+  else VEON_RING_SK(2, 4, 6, 3, 3);              /* 192 x 192 */
+#undef VEON_RING_SK
+  return launch_status();
+}
+
 void veon_gemm_ring_set(int config) {
   g_gemm_ring = config & 0xff;
   if (config < 0) g_gemm_ring = -1;
@@ -1390,12 +1510,17 @@ int veon_vit_attention(const void* qkv_bf16, const float* bias,
 }
 
 
+constexpr int kSplitKSyncInts = 1024;
+
 int64_t veon_vit_block_workspace_bytes(int B, int T, int d, int mlp_dim) {
   if (B <= 0 || T <= 0 || d <= 0 || mlp_dim <= 0) return 0;
-  // h [M,d] + qkv [M,3d] + o [M,d] + u [M,mlp], bf16, each 256-B aligned
+  // h [M,d] + qkv [M,3d] + o [M,d] + u [M,mlp], bf16, each 256-B aligned, + the sync
+  // words of the split-K fc2 (kSplitKSyncInts ints: ZERO when the workspace is first
+  // used, left zero by every call)
   const int64_t M = (int64_t)B * T;
   auto al = [](int64_t v) { return (v + 255) / 256 * 256; };
-  return al(M * d * 2) + al(M * 3 * d * 2) + al(M * d * 2) + al(M * mlp_dim * 2);
+  return al(M * d * 2) + al(M * 3 * d * 2) + al(M * d * 2) + al(M * mlp_dim * 2) +
+         kSplitKSyncInts * 4;
 }
 
 int veon_vit_block(float* x, const veon_vit_block_weights* w,
@@ -1422,6 +1547,8 @@ int veon_vit_block(float* x, const veon_vit_block_weights* w,
   void* o = p;
   p += al(M64 * d * 2);
   void* u = p;
+  p += al(M64 * w->mlp_dim * 2);
+  int* sync_words = reinterpret_cast<int*>(p);
   int st;
   if ((st = veon_vit_layernorm(x, w->ln1_w, w->ln1_b, h, M, d, w->ln1_eps, stream)))
     return st;
@@ -1439,6 +1566,15 @@ int veon_vit_block(float* x, const veon_vit_block_weights* w,
   if ((st = veon_vit_gemm(h, w->w_fc1, w->b_fc1, nullptr, nullptr, u, M, w->mlp_dim,
                           d, w->act, stream)))
     return st;
+  // fc2: split-K where it was measured to win (MI355X, M = 5406: ViT-L's 1024 x 4096
+  // 66.9 vs 71.0 us; ViT-B's 768 x 3072 LOSES, 49.8 vs 41.8 us, and stays unsplit); the
+  // qkv buffer is free by now and serves as the slab
+  const int64_t slab_need = (g_gemm_ring < 0 && w->mlp_dim >= 4096)
+                                ? veon_vit_gemm_splitk_plan(M, d, w->mlp_dim, nullptr)
+                                : 0;
+  if (slab_need > 0 && slab_need <= al(M64 * 3 * d * 2))
+    return veon_vit_gemm_splitk(u, w->w_fc2, w->b_fc2, w->gamma2, x, M, d, w->mlp_dim, qkv,
+                                al(M64 * 3 * d * 2), sync_words, kSplitKSyncInts, stream);
   return veon_vit_gemm(u, w->w_fc2, w->b_fc2, w->gamma2, x, nullptr, M, d,
                        w->mlp_dim, EPI_RESID, stream);
 }

@@ -66,6 +66,20 @@ def camera_matrices(sensor2ego, cam2imgs, post_rots):
     return pri, comb, trans
 
 
+def sensor2keyego(sensor2ego, ego2global):
+    """(B,N,4,4) x 2 -> (B,N,4,4): inverse(ego2global[:, 0]) @ ego2global @ sensor2ego in
+    double precision, one launch (csrc k_sensor2keyego)."""
+    dev = _lib.require_device(sensor2ego, ego2global)
+    B, N = sensor2ego.shape[:2]
+    s2e, e2g = _f32c(sensor2ego), _f32c(ego2global)
+    out = torch.empty((B, N, 4, 4), dtype=torch.float32, device=dev)
+    with _lib.on_device(dev):
+        st = _lib.lib().veon_sensor2keyego(B, N, _lib.ptr(s2e), _lib.ptr(e2g), _lib.ptr(out),
+                                           _lib.stream_ptr(dev))
+    _lib.check(st, 'veon_sensor2keyego')
+    return out
+
+
 class Prepared:
     """Full-capacity device buffers of one prepare call (no host sync yet).
     ``vstart``: the dense voxel table of the row pool kernels (None when the call

@@ -88,6 +88,13 @@ class AlignNetOcc3D(nn.Module):
     def prepare_meta(self, img_metas):
         N = self.num_camera
         sensor2egos, ego2globals, intrins, post_rots, post_trans, bda = img_metas
+        if (self.num_frame == 1 and sensor2egos.is_cuda and not torch.is_grad_enabled()):
+            # one frame at inference: the 4x4 algebra in ONE launch
+            from ... import lss_prepare_hip
+            s2k = lss_prepare_hip.sensor2keyego(sensor2egos.reshape(-1, N, 4, 4),
+                                                ego2globals.reshape(-1, N, 4, 4))
+            return [s2k, ego2globals.view(-1, N, 4, 4), intrins.view(-1, N, 3, 3),
+                    post_rots.view(-1, N, 3, 3), post_trans.view(-1, N, 3), bda[0]]
         sensor2egos = sensor2egos.view(-1, self.num_frame, N, 4, 4)
         ego2globals = ego2globals.view(-1, self.num_frame, N, 4, 4)
         keyego2global = ego2globals[:, 0, 0, ...].unsqueeze(1).unsqueeze(1)

@@ -134,12 +134,14 @@ class _HipClipWeights:
             self.act)
 
 
-def run_blocks(blocks, x_lnd, attn_masks=None, cache=None):
+def run_blocks(blocks, x_lnd, attn_masks=None, cache=None, keep=None):
     """Run ``blocks`` over x (L, N, D).  On a ROCm device in no-grad eval mode
     the MFMA kernels are used (one transpose in, one out); otherwise the torch
     blocks.  attn_masks: None or one additive mask per block, each
     (N*heads, L, L) / (N, heads, L, L) / (L, L).  Returns the list of per-block
-    outputs (L, N, D)."""
+    outputs (L, N, D).  ``keep``: indices of the blocks whose output the caller reads
+    (the last one always is); the native path leaves the others as None instead of
+    copying the stream out after every block."""
     L, N, D = x_lnd.shape
     hip = (x_lnd.is_cuda and not torch.is_grad_enabled()
            and not any(b.training for b in blocks)
@@ -176,7 +178,10 @@ def run_blocks(blocks, x_lnd, attn_masks=None, cache=None):
         if ws is None:
             ws = vit_ops.block_workspace(N, L, D, w.packed.mlp_dim, s.device)
         vit_ops.block_forward_(s, w.packed, N, L, ws, m)
-        outs.append(s.view(N, L, D).permute(1, 0, 2).contiguous())
+        if keep is None or i in keep or i == len(blocks) - 1:
+            outs.append(s.view(N, L, D).permute(1, 0, 2).contiguous())
+        else:
+            outs.append(None)
     return outs
 
 
@@ -256,12 +261,15 @@ class ClipVisualTrunk(nn.Module):
         x = torch.cat([cls, x], dim=1) + self._pos_embed(h, w).to(x.dtype)
         return self.ln_pre(x).permute(1, 0, 2), (h, w)     # LND
 
-    def forward(self, x, last_layer_idx=-1, attn_masks=None):
-        """-> (list of per-block token tensors (L,N,D), (h, w))."""
+    def forward(self, x, last_layer_idx=-1, attn_masks=None, taps=None):
+        """-> (list of per-block token tensors (L,N,D), (h, w)); entry 0 = the tokens
+        after ``ln_pre``, entry i = the output of block i.  ``taps``: the entries the
+        caller reads (None = all); untapped entries may come back as None."""
         t, hw = self.tokens(x)
         blocks = list(self.resblocks if last_layer_idx == -1
                       else self.resblocks[:last_layer_idx])
-        return [t] + run_blocks(blocks, t, attn_masks, self._hip_cache), hw
+        keep = None if taps is None else {i - 1 for i in taps if i >= 1}
+        return [t] + run_blocks(blocks, t, attn_masks, self._hip_cache, keep), hw
 
 
 class ClipRecHead(nn.Module):
@@ -386,7 +394,10 @@ class ClipRecHead(nn.Module):
         new[:, :, 1:, 1:] = attn
         return new.reshape(B * H, L + 1, L + 1)
 
-    def update_remaining_clip_feats(self, clip_outputs, offsets=None, attns=None):
+    def update_remaining_clip_feats(self, clip_outputs, offsets=None, attns=None,
+                                    keep_layers=None):
+        """``keep_layers`` (veon_amd extension): the CLIP layers the caller reads
+        afterwards (None = every tail layer, as the reference saves them)."""
         k0 = self.first_layer_idx
         cls_token = clip_outputs['%d_cls_token' % k0]
         x = clip_outputs[k0]
@@ -412,9 +423,13 @@ class ClipRecHead(nn.Module):
                         self._save(clip_outputs, a + k0, x, hw)
             masks = None if attns is None else \
                 [self.build_attn_bias(attns[t]) for t in range(a, b)]
-            outs = run_blocks(list(self.resblocks)[a:b], x, masks, self._hip_cache)
+            keep = None if keep_layers is None else \
+                {t - a for t in range(a, b) if t + k0 + 1 in keep_layers}
+            outs = run_blocks(list(self.resblocks)[a:b], x, masks, self._hip_cache, keep)
             for t, o in zip(range(a, b), outs):
-                self._save(clip_outputs, t + k0 + 1, o, hw)
+                if o is not None and (keep_layers is None or t + k0 + 1 in keep_layers
+                                      or t + 1 == nblk):
+                    self._save(clip_outputs, t + k0 + 1, o, hw)
             x = outs[-1]
         clip_outputs['clip_feat_proj'] = torch.einsum(
             'bchw,cd->bdhw', clip_outputs[nblk + k0], self.proj)

@@ -134,13 +134,32 @@ class VeonOccupancyPath(nn.Module):
         then the CLIP tail with the HSA attention biases -> the reference's
         ``ClipOutput`` dict (+ 'supp')."""
         x = F.interpolate(img, scale_factor=0.5, mode='bilinear', align_corners=False)
-        outs, hw = self.clip_trunk(x, last_layer_idx=self.clip_first_tail)
+        outs, hw = self.clip_trunk(x, last_layer_idx=self.clip_first_tail,
+                                   taps=self._clip_taps())
         feats = {}
         for i, t in enumerate(outs):
-            ClipRecHead._save(feats, i, t, hw)
+            if t is not None:
+                ClipRecHead._save(feats, i, t, hw)
         _, attns, supp = self.hsa(img, feats)
-        feats = self.clip_rec_head.update_remaining_clip_feats(feats, None, attns)
+        last = self.clip_first_tail + len(self.clip_rec_head.resblocks)
+        feats = self.clip_rec_head.update_remaining_clip_feats(
+            feats, None, attns, keep_layers={last} | self._lift_layers())
         return feats, supp
+
+    def _lift_layers(self):
+        return {src for src, _ in self.occ_decoder.fusion_map.values()}
+
+    def _clip_taps(self):
+        """The CLIP layers anything downstream reads: the HSA network's cross-attention
+        / add sources, the side adapter's fusion sources, the decoder's lifting sources,
+        the recognition head's first layer (and layer 1, whose SHAPE the HSA network
+        and the decoder read).  The trunk copies only those out of its stream."""
+        taps = {0, 1, self.clip_first_tail} | self._lift_layers()
+        for a, b in self.hsa.cr_map.values():
+            taps |= {a, b}
+        if self.side_adapter_network is not None:
+            taps |= set(self.side_adapter_network.fusion_map.values())
+        return {t for t in taps if 0 <= t <= self.clip_first_tail}
 
     def forward_2d(self, images):
         """The 2-D open-vocabulary segmentation branch (san_in_veon_temporal.py:

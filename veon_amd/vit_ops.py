@@ -183,8 +183,36 @@ class BlockWeights:
 
 
 def block_workspace(B, T, d, mlp_dim, device):
+    """Workspace of ``veon_vit_block``.  It ends in the sync words of the split-K fc2
+    (4 KiB), which every call expects zero and leaves zero: only those are cleared."""
     n = _lib.lib().veon_vit_block_workspace_bytes(B, T, d, mlp_dim)
-    return torch.empty(n, dtype=torch.uint8, device=device)
+    ws = torch.empty(n, dtype=torch.uint8, device=device)
+    ws[n - 4096:].zero_()
+    return ws
+
+
+def linear_residual_splitk_(resid, a, w, bias=None, gamma=None, workspace=None):
+    """``linear_residual_`` by the split-K kernel (fc2 shapes); raises when the shape is
+    not one ``veon_vit_gemm_splitk_plan`` splits.  ``workspace``: (slab uint8 tensor,
+    zeroed int32 sync tensor) to reuse; allocated when None."""
+    dev = _dev(resid, a, w)
+    K = a.shape[-1]
+    M = a.numel() // K
+    N = w.shape[0]
+    L = _lib.lib()
+    need = L.veon_vit_gemm_splitk_plan(M, N, K, None)
+    if need == 0:
+        raise _lib.VeonHipError('no split-K plan for %d x %d x %d' % (M, N, K))
+    if workspace is None:
+        workspace = (torch.empty(need, dtype=torch.uint8, device=dev),
+                     torch.zeros(1024, dtype=torch.int32, device=dev))
+    slab, sync = workspace
+    with _lib.on_device(dev):
+        st = L.veon_vit_gemm_splitk(_lib.ptr(a), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(gamma),
+                                    _lib.ptr(resid), M, N, K, _lib.ptr(slab), slab.numel(),
+                                    _lib.ptr(sync), sync.numel(), _lib.stream_ptr(dev))
+    _lib.check(st, 'veon_vit_gemm_splitk')
+    return resid
 
 
 def block_forward_(x, w, B, T, ws, bias=None):
