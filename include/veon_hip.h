@@ -488,6 +488,14 @@ int veon_vit_attention(const void *qkv_bf16, const float *bias,
                        int64_t bias_batch_stride, int64_t bias_head_stride,
                        void *out_bf16, int B, int T, int H, int head_dim,
                        void *stream);
+/* The same with q ALSO multiplied by log2(e) (folded into the projection weights next
+ * to head_dim^-0.5): the scores arrive in the exp2 domain and the kernel spends no
+ * instruction on scaling them (the form veon_vit_block uses when
+ * veon_vit_block_weights.q_log2 is set).  bias stays in natural-log units. */
+int veon_vit_attention_log2(const void *qkv_bf16, const float *bias,
+                            int64_t bias_batch_stride, int64_t bias_head_stride,
+                            void *out_bf16, int B, int T, int H, int head_dim,
+                            void *stream);
 
 /*
  * The fused pool + max-pool writing straight into the Conv3d body's input: the
@@ -530,6 +538,8 @@ typedef struct veon_vit_block_weights {
   const float *b_fc2, *gamma2;
   float ln1_eps, ln2_eps;
   int mlp_dim, act;
+  int q_log2;   /* 1: w_qkv / b_qkv's q rows carry head_dim^-0.5 * log2(e) (attention in
+                   the exp2 domain, veon_vit_attention_log2); 0: head_dim^-0.5 only */
 } veon_vit_block_weights;
 /*
  * Split-K form of the residual GEMM (resid += gamma * (a @ w^T + bias)) for fc2-shaped

@@ -139,43 +139,132 @@ def test_gemm_layerscale_residual_inplace():
                                rtol=1e-4, atol=1e-4)
 
 
-def _ref_attention(qkv, H, bias=None):
+def _ref_attention(qkv, H, bias=None, q_log2=False, dtype=torch.float32):
     B, T, _ = qkv.shape
-    q, k, v = qkv.float().view(B, T, 3, H, 64).permute(2, 0, 3, 1, 4)
+    q, k, v = qkv.to(dtype).view(B, T, 3, H, 64).permute(2, 0, 3, 1, 4)
+    if q_log2:
+        q = q / vit_ops.LOG2E
     s = q @ k.transpose(-1, -2)
     if bias is not None:
-        s = s + bias
+        s = s + bias.to(dtype)
     return (s.softmax(-1) @ v).transpose(1, 2).reshape(B, T, H * 64)
 
 
+def _qkv(B, T, H, seed, scale=0.5, q_log2=False):
+    """Packed qkv as the projection GEMM leaves it; ``q_log2``: q also carries log2(e)
+    (the packers fold it into the weights), the reference takes it out again."""
+    x = _rand(B, T, 3 * H * 64, seed=seed) * scale
+    if q_log2:
+        x.view(B, T, 3, H * 64)[:, :, 0] *= vit_ops.LOG2E
+    return x.to(torch.bfloat16)
+
+
+@pytest.mark.parametrize('q_log2', [False, True])
 @pytest.mark.parametrize('B,T,H', [(2, 901, 12), (1, 64, 1), (1, 65, 2),
                                    (3, 17, 3), (1, 705, 12), (1, 300, 16)])
-def test_attention(B, T, H):
-    qkv = (_rand(B, T, 3 * H * 64, seed=16) * 0.5).to(torch.bfloat16)
-    got = vit_ops.attention(qkv, H).float()
-    ref = _ref_attention(qkv, H)
+def test_attention(B, T, H, q_log2):
+    qkv = _qkv(B, T, H, 16, q_log2=q_log2)
+    got = vit_ops.attention(qkv, H, q_log2=q_log2).float()
+    ref = _ref_attention(qkv, H, q_log2=q_log2)
     # P is rounded to bf16 before P.V (2^-9 relative on each weight), output bf16
     torch.testing.assert_close(got, ref, rtol=2 ** -7, atol=4e-3)
 
 
-def test_attention_with_bias_and_masking():
+@pytest.mark.parametrize('q_log2', [False, True])
+def test_attention_with_bias_and_masking(q_log2):
     B, T, H = 2, 130, 4
-    qkv = (_rand(B, T, 3 * H * 64, seed=17) * 0.5).to(torch.bfloat16)
+    qkv = _qkv(B, T, H, 17, q_log2=q_log2)
     bias = _rand(B, H, T, T, seed=18)
     bias[:, :, :, 100:] = float('-inf')     # masked keys (attn_mask style)
-    got = vit_ops.attention(qkv, H, bias).float()
-    ref = _ref_attention(qkv, H, bias)
+    got = vit_ops.attention(qkv, H, bias, q_log2=q_log2).float()
+    ref = _ref_attention(qkv, H, bias, q_log2)
     torch.testing.assert_close(got, ref, rtol=2 ** -7, atol=4e-3)
     # head-broadcast bias
     b1 = bias[:1, :1].contiguous()
-    got = vit_ops.attention(qkv, H, b1).float()
-    torch.testing.assert_close(got, _ref_attention(qkv, H, b1), rtol=2 ** -7,
+    got = vit_ops.attention(qkv, H, b1, q_log2=q_log2).float()
+    torch.testing.assert_close(got, _ref_attention(qkv, H, b1, q_log2), rtol=2 ** -7,
+                               atol=4e-3)
+    # a whole 64-key tile masked in front of live keys (its row maximum is -inf)
+    b2 = _rand(B, H, T, T, seed=19)
+    b2[:, :, :, :64] = float('-inf')
+    got = vit_ops.attention(qkv, H, b2, q_log2=q_log2).float()
+    torch.testing.assert_close(got, _ref_attention(qkv, H, b2, q_log2), rtol=2 ** -7,
                                atol=4e-3)
 
 
-@pytest.mark.parametrize('act,with_gamma,with_bias', [(vit_ops.EPI_GELU, True, False),
-                                                      (vit_ops.EPI_QUICKGELU, False, True)])
-def test_whole_block_call_equals_the_seven_ops(act, with_gamma, with_bias):
+@pytest.mark.parametrize('q_log2', [False, True])
+@pytest.mark.parametrize('with_bias', [False, True])
+def test_attention_reference_maximum_moves(q_log2, with_bias):
+    """The kernel forms its scores relative to a per-query reference maximum that is set
+    by tile 0 and then moves only when a tile stands more than 8 (log2 units) above it:
+    a rare, data-dependent branch that bounded random data never takes.  Force it
+    (cdna_hip_programming.md rule 26): spike chosen keys against chosen queries so that
+    the maximum jumps at tiles 1, 3, the last full tile and the ragged tail tile, by
+    amounts on both sides of the threshold; make tile 0 itself sit far below zero for
+    some queries (the reference has to move DOWN there) and far above for others.
+    Full-tensor fp64 reference."""
+    B, T, H = 2, 333, 3            # six 64-key tiles, the last with 13 keys
+    x = _rand(B, T, 3 * H * 64, seed=41) * 0.4
+    v = x.view(B, T, 3, H, 64)
+    q, k = v[:, :, 0], v[:, :, 1]
+    unit = torch.zeros(64, device=DEV)
+    unit[5] = 1.0
+    # queries 0..95 get a large component along e5; keys pick it up with chosen gains
+    q[:, :96, :, :] = q[:, :96, :, :] * 0.2 + 3.0 * unit
+    gains = {70: 2.0, 200: 4.5, 300: 7.0, 328: 9.5}     # key -> extra score / 3.0
+    for key, g in gains.items():
+        k[:, key, :, :] = k[:, key, :, :] * 0.2 + g * unit
+    # queries 100..131: every score of tile 0 far below zero, later tiles near zero
+    k[:, :64, 1, :] -= 0.0
+    q[:, 100:132, 1, :] = 2.0 * unit
+    k[:, :64, 1, 5] = -40.0
+    # queries 140..171: tile 0 far above zero
+    q[:, 140:172, 2, :] = 2.0 * unit
+    k[:, :64, 2, 5] = 30.0
+    if q_log2:
+        q *= vit_ops.LOG2E
+    qkv = x.to(torch.bfloat16)
+    bias = _rand(B, H, T, T, seed=42) * 3 if with_bias else None
+    got = vit_ops.attention(qkv, H, bias, q_log2=q_log2).double()
+    ref = _ref_attention(qkv, H, bias, q_log2, dtype=torch.float64)
+    # the branch really is exercised: the running maximum of the spiked queries rises by
+    # more than the threshold at several tiles
+    qq, kk = qkv.double().view(B, T, 3, H, 64)[:, :, 0], qkv.double().view(B, T, 3, H, 64)[:, :, 1]
+    sc = torch.einsum('bqhd,bkhd->bhqk', qq, kk) * (1.0 if q_log2 else vit_ops.LOG2E)
+    if bias is not None:
+        sc = sc + bias.double() * vit_ops.LOG2E
+    tmax = torch.stack([sc[..., i:i + 64].amax(-1) for i in range(0, T, 64)], -1)
+    rises = ((tmax[..., 1:] - tmax.cummax(-1).values[..., :-1]) > 8).sum().item()
+    assert rises > 500, rises
+    assert (tmax[..., 0] < -60).any() and (tmax[..., 0] > 60).any()
+    torch.testing.assert_close(got, ref, rtol=2 ** -6, atol=6e-3)
+
+
+def test_attention_is_deterministic_under_load():
+    """Regression for a fault seen while the exp2-domain kernel was built: with the move
+    of the reference written as scalar code, hipcc packed it into v_pk_add_f32 with
+    operand crossing (op_sel:[0,1]), and on a full chip (B6 T901 H12, 576 workgroups)
+    the low halves in lanes 48-63 now and then kept the unshifted score -- a wrong
+    softmax weight for one key of one query, in EVERY launch of this input, different
+    queries each time.  The kernel is deterministic by construction, so: same input,
+    many launches, bit-identical outputs, and correct against fp32."""
+    B, T, H = 6, 901, 12
+    qkv = _qkv(B, T, H, 43, scale=0.9, q_log2=True)      # reference moves for ~20 % of queries
+    outs = torch.empty(B, T, H * 64, dtype=qkv.dtype, device=DEV)
+    first = vit_ops.attention(qkv, H, q_log2=True).clone()
+    for _ in range(60):
+        vit_ops.attention(qkv, H, out=outs, q_log2=True)
+        assert torch.equal(outs, first)
+    ref = _ref_attention(qkv, H, q_log2=True)
+    err = (first.float() - ref).norm(dim=-1) / ref.norm(dim=-1)
+    assert err.max().item() < 0.02, err.max().item()
+
+
+@pytest.mark.parametrize('act,with_gamma,with_bias,q_log2',
+                         [(vit_ops.EPI_GELU, True, False, True),
+                          (vit_ops.EPI_QUICKGELU, False, True, False),
+                          (vit_ops.EPI_QUICKGELU, False, True, True)])
+def test_whole_block_call_equals_the_seven_ops(act, with_gamma, with_bias, q_log2):
     """veon_vit_block (one native call per block) is exactly the sequence
     LN -> qkv -> attention -> proj(+res) -> LN -> fc1(act) -> fc2(+res)."""
     torch.manual_seed(5)
@@ -200,14 +289,14 @@ def test_whole_block_call_equals_the_seven_ops(act, with_gamma, with_bias):
     x = x0.clone()
     h = vit_ops.layernorm(x, *n1)
     qkv = vit_ops.linear(h, w_qkv, b_qkv)
-    o = vit_ops.attention(qkv.view(B, T, -1), H, bias)
+    o = vit_ops.attention(qkv.view(B, T, -1), H, bias, q_log2=q_log2)
     vit_ops.linear_residual_(x, o.view(B * T, -1), w_proj, b_proj, g1)
     h = vit_ops.layernorm(x, *n2)
     u = vit_ops.linear(h, w_fc1, b_fc1, act)
     vit_ops.linear_residual_(x, u, w_fc2, b_fc2, g2)
     # one call
     w = vit_ops.BlockWeights(H, n1, w_qkv, b_qkv, w_proj, b_proj, g1, n2, w_fc1,
-                             b_fc1, w_fc2, b_fc2, g2, act)
+                             b_fc1, w_fc2, b_fc2, g2, act, q_log2=q_log2)
     ws = vit_ops.block_workspace(B, T, d, mlp, dev)
     y = vit_ops.block_forward_(x0.clone(), w, B, T, ws, bias)
     assert torch.equal(x, y)

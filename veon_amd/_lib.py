@@ -41,7 +41,8 @@ class VitBlockWeights(ctypes.Structure):
                 ('w_fc2', ctypes.c_void_p), ('b_fc2', ctypes.c_void_p),
                 ('gamma2', ctypes.c_void_p),
                 ('ln1_eps', ctypes.c_float), ('ln2_eps', ctypes.c_float),
-                ('mlp_dim', ctypes.c_int), ('act', ctypes.c_int)]
+                ('mlp_dim', ctypes.c_int), ('act', ctypes.c_int),
+                ('q_log2', ctypes.c_int)]
 
 
 _SIGNATURES = {
@@ -84,6 +85,7 @@ _SIGNATURES = {
     'veon_vit_patchify': (_ci, [_vp, _vp] + [_ci] * 7 + [_vp]),
     'veon_vit_gemm': (_ci, [_vp] * 6 + [_ci] * 4 + [_vp]),
     'veon_vit_attention': (_ci, [_vp, _vp, _i64, _i64, _vp, _ci, _ci, _ci, _ci, _vp]),
+    'veon_vit_attention_log2': (_ci, [_vp, _vp, _i64, _i64, _vp, _ci, _ci, _ci, _ci, _vp]),
     'veon_vit_block_workspace_bytes': (_i64, [_ci] * 4),
     'veon_vit_gemm_splitk_plan': (_i64, [_ci, _ci, _ci, _vp]),
     'veon_vit_gemm_splitk': (_ci, [_vp] * 5 + [_ci] * 3 + [_vp, _i64, _vp, _i64, _vp]),

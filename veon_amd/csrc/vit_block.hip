@@ -817,28 +817,51 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_g32(
 
 // ------------------------------------------------------------------ attention
 // qkv: [B, T, 3, H, 64] bf16 (the packed output of the qkv projection, q already
-// scaled by head_dim^-0.5 through the weights).  out: [B, T, H*64] bf16.
+// scaled by head_dim^-0.5 through the weights; LOG2Q: also by log2(e), so that the
+// scores arrive in the exp2 domain).  out: [B, T, H*64] bf16.
 // Optional additive bias [B or 1][H or 1][T][T] fp32 (CLIP tail; strides given).
 // Workgroup = 256 threads = 4 waves, 32 queries per wave.  K/V tiles of 64 keys
 // go global -> LDS by DMA (global_load_lds_dwordx4, no VGPR staging) into a
 // double buffer whose 16-byte chunks are XOR-swizzled by the row exactly as in
 // the GEMM; one barrier per tile.  S^T = K.Q^T so the softmax statistics of a
 // query are lane-local; K fragments are 16-B LDS reads, V^T fragments come from
-// the hardware transposing read ds_read_b64_tr_b16.  With head_dim 64 the
-// kernel is VALU-bound (32 exp2 + ~100 other VALU ops against 32 MFMAs per wave
-// and tile), so the loop body is kept lean: bias and tail masking are compiled
-// out of the common path, the accumulator rescale is skipped when no running
-// maximum moved, exp2 takes its scale by one FMA.
+// the hardware transposing read ds_read_b64_tr_b16.
+// With head_dim 64 the loop is bound by vector issue (32 exp2 against 36 MFMAs per
+// wave and tile), so the softmax is reduced to what cannot be avoided:
+//  * the scores are formed RELATIVE to a per-query reference maximum: it is the C
+//    operand of the first S^T MFMA (LOG2Q), so exp2 applies to the accumulator as
+//    it is -- no scale, no subtraction;
+//  * the reference moves only when a tile stands more than kAttRise above it
+//    (guide T13); the usual tile has no rescale of O at all;
+//  * the row sums come from the matrix core (a fifth V^T "d tile" of ones).
+// Per wave and tile that is 32 v_exp + 16 v_cvt_pk + ~20 v_max3 + a dozen others
+// (was ~200 vector instructions with the running maximum of round 2).
 constexpr int HD = 64;        // head dim
 constexpr int QT = 2;         // 16-query tiles per wave
 constexpr int AQ = 16 * QT;   // queries per wave
 constexpr int AK = 64;        // keys per LDS tile
 constexpr int KV_ELEMS = AK * HD;  // one operand tile (8 KiB)
+constexpr float kAttRise = 8.f;    // log2 units a score may stand above the reference maximum
 
 typedef bf16x4 __attribute__((address_space(3))) lds_bf16x4;
 
-template <bool HAS_BIAS>
-__global__ __launch_bounds__(256, 2) void k_attention(
+// max over the four 16-lane rows of a wave without touching LDS: the gfx950
+// row-swap instructions exchange halves (permlane32) / odd and even rows
+// (permlane16) of two registers, so two copies of x come back as x and its
+// partner.  Written as asm: through the builtin, hipcc 7.2 folds
+// max(result0, result1) to result0 (seen in the ISA: both v_max dropped, rows
+// disagree on their maximum).  The s_nop are the VALU-write -> swap and swap ->
+// VALU-read wait states the compiler would otherwise insert itself.
+__device__ __forceinline__ float max_over_rows(float x) {
+  float a = x, b = x;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+  a = b = fmaxf(a, b);
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+  return fmaxf(a, b);
+}
+
+template <bool HAS_BIAS, bool LOG2Q>
+__global__ __launch_bounds__(256, 3) void k_attention(
     const bf16_t* __restrict__ qkv, const float* __restrict__ bias,
     int64_t bias_sb, int64_t bias_sh, bf16_t* __restrict__ out, int T, int H) {
   __shared__ __attribute__((aligned(16))) bf16_t smem[4 * KV_ELEMS];  // [buf][K|V]
@@ -890,14 +913,23 @@ __global__ __launch_bounds__(256, 2) void k_attention(
                                                    ks * 32 + fg * 8);
   }
   f32x4 o[QT][4];  // [q tile][d tile]: O^T[d = 4fg + reg][q = fr]
-  float mrow[QT], lrow[QT];  // running max (log2 domain) and sum per q = fr
+  // ol: the row sums, accumulated by the matrix core as a fifth "d tile" whose V^T
+  // fragment is all ones (every register of a lane = the sum of query fr).
+  // negm: minus the REFERENCE maximum of query fr (log2 domain), in all four
+  // registers: it is the C operand of the first S^T MFMA, so the scores arrive
+  // already shifted.
+  f32x4 ol[QT];
+  float negm[QT];
 #pragma unroll
   for (int i = 0; i < QT; ++i) {
-    mrow[i] = -INFINITY;
-    lrow[i] = 0.f;
+    ol[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    negm[i] = 0.f;
 #pragma unroll
     for (int j = 0; j < 4; ++j) o[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
+  bf16x8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = f2bf(1.f);
   const float* brow[QT];
   if (HAS_BIAS) {
 #pragma unroll
@@ -920,12 +952,13 @@ __global__ __launch_bounds__(256, 2) void k_attention(
   }
 
   const int nt = (T + AK - 1) / AK;
-  auto tile = [&](int t, auto tail_tag) {
+  auto tile = [&](int t, auto tail_tag, float floor_) {
     constexpr bool TAIL = decltype(tail_tag)::value;
     const int k0 = t * AK;
     const bf16_t* sK = smem + (t & 1) * 2 * KV_ELEMS;
     const bf16_t* sV = sK + KV_ELEMS;
-    // S^T tiles: s[i][kt][reg] = S[q = i*16 + fr][key = kt*16 + 4fg + reg]
+    // S^T tiles: s[i][kt][reg] = S[q = i*16 + fr][key = kt*16 + 4fg + reg], in the
+    // log2 domain and relative to the reference maximum
     f32x4 s[QT][4];
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
@@ -935,14 +968,30 @@ __global__ __launch_bounds__(256, 2) void k_attention(
           *reinterpret_cast<const bf16x8*>(sK + kt * 16 * HD + (offK ^ 32));
 #pragma unroll
       for (int i = 0; i < QT; ++i) {
-        f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 a = LOG2Q ? f32x4{negm[i], negm[i], negm[i], negm[i]}
+                        : f32x4{0.f, 0.f, 0.f, 0.f};
         a = mfma_16x16x32(kf0, qf[i][0], a);
         a = mfma_16x16x32(kf1, qf[i][1], a);
         s[i][kt] = a;
       }
     }
+    float mx[QT];
 #pragma unroll
     for (int i = 0; i < QT; ++i) {
+      if (!LOG2Q) {
+        // natural-log scores: scale and shift here, on register pairs and with a real
+        // (-m, -m) pair (no operand crossing in the packed FMA, see the move below)
+        f32x2 nn = {negm[i], negm[i]};
+        asm volatile("" : "+v"(nn));
+        const f32x2 ll = {kLog2e, kLog2e};
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+          f32x2 lo = {s[i][kt][0], s[i][kt][1]}, hi = {s[i][kt][2], s[i][kt][3]};
+          lo = __builtin_elementwise_fma(lo, ll, nn);
+          hi = __builtin_elementwise_fma(hi, ll, nn);
+          s[i][kt] = f32x4{lo[0], lo[1], hi[0], hi[1]};
+        }
+      }
       if (HAS_BIAS) {
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt)
@@ -950,7 +999,7 @@ __global__ __launch_bounds__(256, 2) void k_attention(
           for (int r = 0; r < 4; ++r) {
             int key = k0 + kt * 16 + fg * 4 + r;
             if (TAIL) key = key < T ? key : T - 1;
-            s[i][kt][r] += brow[i][key];
+            s[i][kt][r] = fmaf(brow[i][key], kLog2e, s[i][kt][r]);
           }
       }
       if (TAIL) {
@@ -960,36 +1009,55 @@ __global__ __launch_bounds__(256, 2) void k_attention(
           for (int r = 0; r < 4; ++r)
             if (k0 + kt * 16 + fg * 4 + r >= T) s[i][kt][r] = -INFINITY;
       }
-      float mx = s[i][0][0];
+      float m = s[i][0][0];
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[i][kt][r]);
-      mx = fmaxf(mx, __shfl_xor(mx, 16));
-      mx = fmaxf(mx, __shfl_xor(mx, 32));
-      // log2 domain: p = exp2(s*log2e - m), m = max(s)*log2e
-      const float mnew = fmaxf(mrow[i], mx * kLog2e);
-      const float msafe = (mnew == -INFINITY) ? 0.f : mnew;
-      const float corr = __builtin_amdgcn_exp2f(mrow[i] - msafe);
-      mrow[i] = mnew;
-      float rs = 0.f;
+        for (int r = 0; r < 4; ++r) m = fmaxf(m, s[i][kt][r]);
+      mx[i] = m;
+    }
+    // The reference maximum of a query moves only when a score of this tile stands
+    // more than kAttRise above it (or at tile 0, which sets it).  The decision is per
+    // query (the row maximum is formed over the four lane rows first, so the lanes
+    // of a query agree), and when any query of the wave moves, everything that still
+    // stands at the old reference -- O, the row sums, the reference and this tile's
+    // scores -- moves with it, each exactly once and BEFORE any score of the tile is
+    // exponentiated (guide T13's textbook order); d = 0 leaves a query as it is.
+    float d[QT];
+    bool any_move = false;
 #pragma unroll
-      for (int kt = 0; kt < 4; ++kt)
+    for (int i = 0; i < QT; ++i) {
+      const float m = max_over_rows(mx[i]);
+      d[i] = (m > kAttRise || m < floor_) ? m : 0.f;
+      if (d[i] == -INFINITY) d[i] = 0.f;  // a fully masked row (bias of -inf)
+      any_move |= d[i] != 0.f;
+    }
+    if (__any(any_move)) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float p = __builtin_amdgcn_exp2f(fmaf(s[i][kt][r], kLog2e, -msafe));
-          s[i][kt][r] = p;
-          rs += p;
-        }
-      rs += __shfl_xor(rs, 16);
-      rs += __shfl_xor(rs, 32);
-      lrow[i] = lrow[i] * corr + rs;
-      if (__any(corr != 1.f)) {  // wave-uniform: usually false after a few tiles
+      for (int i = 0; i < QT; ++i) {
+        // (tile 0 may move DOWN by any amount: O and the sums are 0 there, keep corr finite)
+        const float corr = __builtin_amdgcn_exp2f(fminf(-d[i], 100.f));
+        // Both factors as REAL register pairs (x, x), and the updates written on
+        // pairs: left to itself hipcc packs the scalar form into v_pk_add_f32 /
+        // v_pk_mul_f32 with op_sel operand crossing (one half reading the other dword
+        // of the source pair), and with "op_sel:[0,1]" the low halves in lanes 48-63
+        // came back unshifted now and then (a wrong P for one key of one query; 300 of
+        // 300 launches of B6 T901 H12 had such a tile, none in 3000 without the
+        // crossing -- DESIGN 4b).  The empty asm keeps the pairs from being folded
+        // back into one register.
+        f32x2 dd = {d[i], d[i]}, cc = {corr, corr};
+        asm volatile("" : "+v"(dd), "+v"(cc));
+        auto on_pairs = [](f32x4& x, f32x2 f, bool mul) {
+          f32x2 lo = {x[0], x[1]}, hi = {x[2], x[3]};
+          if (mul) { lo *= f; hi *= f; } else { lo -= f; hi -= f; }
+          x = f32x4{lo[0], lo[1], hi[0], hi[1]};
+        };
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          o[i][j][0] *= corr; o[i][j][1] *= corr;
-          o[i][j][2] *= corr; o[i][j][3] *= corr;
-        }
+        for (int j = 0; j < 4; ++j) on_pairs(o[i][j], cc, true);
+        on_pairs(ol[i], cc, true);
+        negm[i] -= d[i];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) on_pairs(s[i][kt], dd, false);
       }
     }
     // O^T += V^T . P^T : MFMA k-slot (8fg + j) <-> key
@@ -1001,11 +1069,16 @@ __global__ __launch_bounds__(256, 2) void k_attention(
 #pragma unroll
       for (int i = 0; i < QT; ++i) {
         typedef unsigned __attribute__((ext_vector_type(4))) u32x4;
+#pragma unroll
+        for (int kt = 2 * kk; kt < 2 * kk + 2; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) s[i][kt][r] = __builtin_amdgcn_exp2f(s[i][kt][r]);
         const u32x4 pk = {pack_bf16(s[i][2 * kk][0], s[i][2 * kk][1]),
                           pack_bf16(s[i][2 * kk][2], s[i][2 * kk][3]),
                           pack_bf16(s[i][2 * kk + 1][0], s[i][2 * kk + 1][1]),
                           pack_bf16(s[i][2 * kk + 1][2], s[i][2 * kk + 1][3])};
         pf[i] = __builtin_bit_cast(bf16x8, pk);
+        ol[i] = mfma_16x16x32(ones, pf[i], ol[i]);
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -1026,13 +1099,19 @@ __global__ __launch_bounds__(256, 2) void k_attention(
   };
 
   __syncthreads();  // tile 0 landed
+  float floor_ = INFINITY;
   for (int t = 0; t < nt; ++t) {
     if (t + 1 < nt) dma((t + 1) & 1, (t + 1) * AK);  // flies under this tile
     if (q0 < T) {  // waves past the last query only feed the DMA and barriers
       if ((t + 1) * AK > T)
-        tile(t, std::true_type{});
+        tile(t, std::true_type{}, floor_);
       else
-        tile(t, std::false_type{});
+        tile(t, std::false_type{}, floor_);
+      // Tile 0 sets the reference (any maximum counts as "below the floor" of +inf);
+      // from then on it only rises.  The empty asm keeps the compiler from peeling
+      // tile 0 out of the loop, which costs 80 registers of copied accumulators.
+      floor_ = -INFINITY;
+      asm volatile("" : "+s"(floor_));
     }
     __syncthreads();  // next tile landed, this one fully consumed
   }
@@ -1040,8 +1119,9 @@ __global__ __launch_bounds__(256, 2) void k_attention(
 #pragma unroll
   for (int i = 0; i < QT; ++i) {
     const int q = q0 + i * 16 + fr;
+    const float l = ol[i][0];
     if (q >= T) continue;
-    const float inv = lrow[i] > 0.f ? 1.f / lrow[i] : 0.f;
+    const float inv = l > 0.f ? 1.f / l : 0.f;
     bf16_t* op = out + ((int64_t)b * T + q) * (int64_t)H * HD + (int64_t)h * HD;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -1488,25 +1568,44 @@ int veon_vit_gemm(const void* a_bf16, const void* w_bf16, const float* bias,
   return launch_status();
 }
 
-int veon_vit_attention(const void* qkv_bf16, const float* bias,
-                       int64_t bias_batch_stride, int64_t bias_head_stride,
-                       void* out_bf16, int B, int T, int H, int head_dim,
-                       void* stream) {
-  if (B <= 0 || T <= 0 || H <= 0 || head_dim != HD || !qkv_bf16 || !out_bf16)
-    return VEON_ERR_BAD_ARG;
+static int attention_launch(const void* qkv_bf16, const float* bias,
+                            int64_t bias_batch_stride, int64_t bias_head_stride,
+                            void* out_bf16, int B, int T, int H, int head_dim, bool q_log2,
+                            void* stream) {
+  if (!qkv_bf16 || !out_bf16 || B <= 0 || T <= 0 || H <= 0) return VEON_ERR_BAD_ARG;
+  if (head_dim != HD) return VEON_ERR_BAD_ARG;
   if (!al16(qkv_bf16) || !al16(out_bf16)) return VEON_ERR_BAD_ARG;
   // the K/V DMA addresses an image's rows with 32-bit byte offsets
   if ((int64_t)T * 3 * H * HD * 2 >= (1ll << 31)) return VEON_ERR_BAD_ARG;
   const dim3 grid((unsigned)((T + 4 * AQ - 1) / (4 * AQ)), (unsigned)H, (unsigned)B);
-#define VEON_LAUNCH_ATT(BIAS)                                                  \
-  hipLaunchKernelGGL((k_attention<BIAS>), grid, dim3(256), 0,                  \
+#define VEON_LAUNCH_ATT(BIAS, LOG2Q)                                           \
+  hipLaunchKernelGGL((k_attention<BIAS, LOG2Q>), grid, dim3(256), 0,           \
                      static_cast<hipStream_t>(stream),                         \
                      static_cast<const bf16_t*>(qkv_bf16), bias,               \
                      bias_batch_stride, bias_head_stride,                      \
                      static_cast<bf16_t*>(out_bf16), T, H)
-  if (bias != nullptr) VEON_LAUNCH_ATT(true); else VEON_LAUNCH_ATT(false);
+  if (q_log2) {
+    if (bias != nullptr) VEON_LAUNCH_ATT(true, true); else VEON_LAUNCH_ATT(false, true);
+  } else {
+    if (bias != nullptr) VEON_LAUNCH_ATT(true, false); else VEON_LAUNCH_ATT(false, false);
+  }
 #undef VEON_LAUNCH_ATT
   return launch_status();
+}
+
+int veon_vit_attention(const void* qkv_bf16, const float* bias, int64_t bias_batch_stride,
+                       int64_t bias_head_stride, void* out_bf16, int B, int T, int H,
+                       int head_dim, void* stream) {
+  return attention_launch(qkv_bf16, bias, bias_batch_stride, bias_head_stride, out_bf16, B,
+                          T, H, head_dim, false, stream);
+}
+
+int veon_vit_attention_log2(const void* qkv_bf16, const float* bias,
+                            int64_t bias_batch_stride, int64_t bias_head_stride,
+                            void* out_bf16, int B, int T, int H, int head_dim,
+                            void* stream) {
+  return attention_launch(qkv_bf16, bias, bias_batch_stride, bias_head_stride, out_bf16, B,
+                          T, H, head_dim, true, stream);
 }
 
 
@@ -1555,8 +1654,8 @@ int veon_vit_block(float* x, const veon_vit_block_weights* w,
   if ((st = veon_vit_gemm(h, w->w_qkv, w->b_qkv, nullptr, nullptr, qkv, M, 3 * d, d,
                           EPI_BF16, stream)))
     return st;
-  if ((st = veon_vit_attention(qkv, attn_bias, bias_batch_stride, bias_head_stride,
-                               o, B, T, H, HD, stream)))
+  if ((st = attention_launch(qkv, attn_bias, bias_batch_stride, bias_head_stride, o, B, T,
+                             H, HD, w->q_log2 != 0, stream)))
     return st;
   if ((st = veon_vit_gemm(o, w->w_proj, w->b_proj, w->gamma1, x, nullptr, M, d, d,
                           EPI_RESID, stream)))

@@ -159,8 +159,10 @@ class _HipBlockWeights:
         dev = a.qkv.weight.device
         wq = eff(a.qkv).detach().float().clone()
         bq = vec(a.qkv.bias, 3 * d, dev).clone()
-        wq[:d] *= a.scale          # fold q * scale (attention.py:60)
-        bq[:d] *= a.scale
+        # fold q * scale (attention.py:60) and log2(e): the attention kernel then works
+        # in the exp2 domain without spending an instruction on the scores
+        wq[:d] *= a.scale * vit_ops.LOG2E
+        bq[:d] *= a.scale * vit_ops.LOG2E
         self.heads = a.num_heads
         self.w_qkv, self.b_qkv = vit_ops.to_bf16(wq), bq
         self.w_proj = vit_ops.to_bf16(eff(a.proj).detach().float())
@@ -181,7 +183,7 @@ class _HipBlockWeights:
         self.packed = vit_ops.BlockWeights(
             self.heads, self.n1, self.w_qkv, self.b_qkv, self.w_proj, self.b_proj,
             self.g1, self.n2, self.w_fc1, self.b_fc1, self.w_fc2, self.b_fc2,
-            self.g2, vit_ops.EPI_GELU)
+            self.g2, vit_ops.EPI_GELU, q_log2=True)
 
 
 class DinoVisionTransformer(nn.Module):

@@ -113,8 +113,10 @@ class _HipClipWeights:
         scale = (d // a.num_heads) ** -0.5
         w = a.in_proj_weight.detach().float().clone()
         b = a.in_proj_bias.detach().float().clone()
-        w[:d] *= scale       # F.multi_head_attention_forward scales q
-        b[:d] *= scale
+        # F.multi_head_attention_forward scales q; log2(e) rides along (exp2-domain
+        # attention kernel, BlockWeights(q_log2=True))
+        w[:d] *= scale * vit_ops.LOG2E
+        b[:d] *= scale * vit_ops.LOG2E
         self.heads = a.num_heads
         self.w_qkv, self.b_qkv = vit_ops.to_bf16(w), b.contiguous()
         self.w_proj = vit_ops.to_bf16(a.out_proj.weight.detach().float())
@@ -131,7 +133,7 @@ class _HipClipWeights:
         self.packed = vit_ops.BlockWeights(
             self.heads, self.n1, self.w_qkv, self.b_qkv, self.w_proj, self.b_proj,
             None, self.n2, self.w_fc1, self.b_fc1, self.w_fc2, self.b_fc2, None,
-            self.act)
+            self.act, q_log2=True)
 
 
 def run_blocks(blocks, x_lnd, attn_masks=None, cache=None, keep=None):

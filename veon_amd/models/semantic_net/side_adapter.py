@@ -148,8 +148,8 @@ class _PaddedBlock:
         bq = torch.zeros(3, H, 64, **f32)
         wq[:, :, :hd, :d] = blk.attn.qkv.weight.detach().float().view(3, H, hd, d)
         bq[:, :, :hd] = blk.attn.qkv.bias.detach().float().view(3, H, hd)
-        wq[0] *= hd ** -0.5
-        bq[0] *= hd ** -0.5
+        wq[0] *= hd ** -0.5 * vit_ops.LOG2E     # exp2-domain attention (q_log2)
+        bq[0] *= hd ** -0.5 * vit_ops.LOG2E
         wp = torch.zeros(dp, H, 64, **f32)
         wp[:d, :, :hd] = blk.attn.proj.weight.detach().float().view(d, H, hd)
         w1 = torch.zeros(mp, dp, **f32)
@@ -178,7 +178,7 @@ class _PaddedBlock:
         from ... import vit_ops
         h = vit_ops.layernorm_padded(s, self.n1[0], self.n1[1], self.d, self.n1[2])
         qkv = vit_ops.linear(h, self.w_qkv, self.b_qkv)
-        o = vit_ops.attention(qkv.view(B, T, -1), self.heads)
+        o = vit_ops.attention(qkv.view(B, T, -1), self.heads, q_log2=True)
         vit_ops.linear_residual_(s, o.view(B * T, -1), self.w_proj, self.b_proj)
         h = vit_ops.layernorm_padded(s, self.n2[0], self.n2[1], self.d, self.n2[2])
         u = vit_ops.linear(h, self.w_fc1, self.b_fc1, vit_ops.EPI_GELU)

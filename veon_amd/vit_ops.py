@@ -134,8 +134,12 @@ def linear_residual_(resid, a, w, bias=None, gamma=None):
     return resid
 
 
-def attention(qkv, num_heads, bias=None, out=None):
-    """qkv bf16 [B,T,3*H*64] (q pre-scaled) -> bf16 [B,T,H*64].
+LOG2E = 1.4426950408889634   # folded into q by the packers that set ``q_log2``
+
+
+def attention(qkv, num_heads, bias=None, out=None, q_log2=False):
+    """qkv bf16 [B,T,3*H*64] (q pre-scaled by head_dim^-0.5; ``q_log2``: also by
+    ``LOG2E``, the exp2-domain form of the kernel) -> bf16 [B,T,H*64].
     bias: optional fp32 additive logits, broadcastable [B|1, H|1, T, T]."""
     dev = _dev(qkv)
     B, T, three_d = qkv.shape
@@ -153,9 +157,10 @@ def attention(qkv, num_heads, bias=None, out=None):
         sb = bias.stride(0) if bias.shape[0] > 1 else 0
         sh = bias.stride(1) if bias.shape[1] > 1 else 0
     with torch.cuda.device(dev):
-        st = _lib.lib().veon_vit_attention(
-            _lib.ptr(qkv), _lib.ptr(bias), sb, sh, _lib.ptr(out), B, T, H, hd,
-            _lib.stream_ptr(dev))
+        L = _lib.lib()
+        fn = L.veon_vit_attention_log2 if q_log2 else L.veon_vit_attention
+        st = fn(_lib.ptr(qkv), _lib.ptr(bias), sb, sh, _lib.ptr(out), B, T, H, hd,
+                _lib.stream_ptr(dev))
     _lib.check(st, 'veon_vit_attention')
     return out
 
@@ -165,8 +170,9 @@ class BlockWeights:
     (include/veon_hip.h): keeps the tensors alive and the C struct ready."""
 
     def __init__(self, heads, n1, w_qkv, b_qkv, w_proj, b_proj, g1, n2, w_fc1,
-                 b_fc1, w_fc2, b_fc2, g2, act):
+                 b_fc1, w_fc2, b_fc2, g2, act, q_log2=False):
         self.heads = heads
+        self.q_log2 = bool(q_log2)
         self.keep = (n1[0], n1[1], w_qkv, b_qkv, w_proj, b_proj, g1, n2[0], n2[1],
                      w_fc1, b_fc1, w_fc2, b_fc2, g2)
         for t in self.keep:
@@ -179,7 +185,7 @@ class BlockWeights:
             p(w_proj).value, p(b_proj).value, p(g1).value, p(n2[0]).value,
             p(n2[1]).value, p(w_fc1).value, p(b_fc1).value, p(w_fc2).value,
             p(b_fc2).value, p(g2).value, float(n1[2]), float(n2[2]),
-            int(self.mlp_dim), int(act))
+            int(self.mlp_dim), int(act), int(self.q_log2))
 
 
 def block_workspace(B, T, d, mlp_dim, device):
