@@ -682,6 +682,15 @@ int veon_free_device(void *ptr);
  * HSA network's blocks (highres_side_adaptor.py:108-135, 138-193). */
 int veon_layernorm_f32(const float *x, const float *gamma, const float *beta,
                        float *out, int T, int d, float eps, void *stream);
+/* LayerNorm(x + offset) of (B, L, d) fp32 tokens, where offset is the nearest-neighbour
+ * resize (F.interpolate default mode: src = min(floor(dst * in / out), in - 1), the scale
+ * in fp32) of a coarser map `add` [B][h*w][d] fp32 to the Y x X token map, added to the
+ * LAST Y*X tokens of every sample: the tail of HighresSideAdaptorBlock.forward
+ * (highres_side_adaptor.py:123-135 -- neck_add, interpolate, cat / add, ln_4) in one
+ * pass instead of upsample + add + cat + LayerNorm. */
+int veon_layernorm_f32_add_nearest(const float *x, const float *add, const float *gamma,
+                                   const float *beta, float *out, int B, int L, int d,
+                                   int Y, int X, int h, int w, float eps, void *stream);
 /* the same LayerNorm of (B, Y*X, d) fp32 tokens, written as bf16 into the interior
  * of a zero-haloed channels-last image [B][Y+2][X+2][d] (halo untouched): ln_3
  * followed by the ConvBlock's permute / reshape to a feature map (:113-122, :38-40). */

@@ -305,6 +305,32 @@ def test_whole_block_call_equals_the_seven_ops(act, with_gamma, with_bias, q_log
         vit_ops.block_forward_(x0.clone(), w, B, T, ws[:ws.numel() // 2], bias)
 
 
+@pytest.mark.parametrize('B,L,d,YX,hw', [(2, 64 * 176, 384, (64, 176), (32, 88)),
+                                         (1, 5 * 7 + 3, 128, (5, 7), (3, 3)),
+                                         (3, 6 * 9, 256, (6, 9), (7, 11))])
+def test_layernorm_f32_add_nearest_is_the_torch_sequence(B, L, d, YX, hw):
+    """The fused tail of HighresSideAdaptorBlock (nearest resize of the projected CLIP map,
+    add onto the last Y*X tokens, ln_4) against the reference's own sequence
+    (highres_side_adaptor.py:123-135): interpolate -> reshape / permute -> cat -> LayerNorm;
+    bit-identical to the plain LayerNorm kernel on the torch-composed input (the fused
+    kernel adds in fp32 before the same statistics), up- and down-sampling, with
+    leading tokens that get no offset."""
+    import torch.nn.functional as F
+    (Y, X), (h, w) = YX, hw
+    g = torch.Generator().manual_seed(L + d)
+    x = (torch.randn(B, L, d, generator=g) * 2).to(DEV)
+    add = torch.randn(B, h * w, d, generator=g).to(DEV)
+    wt = (torch.rand(d, generator=g) + 0.5).to(DEV)
+    bs = torch.randn(d, generator=g).to(DEV)
+    off = F.interpolate(add.permute(0, 2, 1).reshape(B, d, h, w), size=(Y, X))
+    off = off.reshape(B, d, -1).permute(0, 2, 1)
+    composed = torch.cat([x[:, :-off.shape[1]], x[:, -off.shape[1]:] + off], 1)
+    got = vit_ops.layernorm_f32_add_nearest(x, add, (Y, X), (h, w), wt, bs, 1e-5)
+    assert torch.equal(got, vit_ops.layernorm_f32(composed.contiguous(), wt, bs, 1e-5))
+    torch.testing.assert_close(got, F.layer_norm(composed, (d,), wt, bs, 1e-5),
+                               rtol=2e-5, atol=2e-5)
+
+
 @pytest.mark.parametrize('T,d', [(1000, 384), (7, 128), (67584, 384), (33, 1024)])
 def test_layernorm_f32_matches_torch(T, d):
     """veon_layernorm_f32 (fp32 in / out, half a wave per row) vs F.layer_norm."""

@@ -107,6 +107,7 @@ _SIGNATURES = {
     'veon_alloc_device_flags': (_ci, [_vp, _i64, ctypes.c_uint]),
     'veon_free_device': (_ci, [_vp]),
     'veon_layernorm_f32': (_ci, [_vp] * 4 + [_ci, _ci, _cf, _vp]),
+    'veon_layernorm_f32_add_nearest': (_ci, [_vp] * 5 + [_ci] * 7 + [_cf, _vp]),
     'veon_layernorm_f32_to_padded': (_ci, [_vp] * 4 + [_ci] * 4 + [_cf, _vp]),
     'veon_image_layernorm_bf16': (_ci, [_vp] * 4 + [_ci] * 5 + [_cf, _vp, _vp]),
     'veon_deform_attention_bf16': (_ci, [_vp] * 4 + [_ci] * 8 + [_vp]),

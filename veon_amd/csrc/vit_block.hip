@@ -1176,21 +1176,43 @@ namespace {
 // PADDED: instead of fp32 rows, write bf16 into the interior of a zero-haloed
 // channels-last image [B][Y+2][X+2][D] (token t = (b, y, x)): LayerNorm + the
 // ConvBlock's input staging in one pass.
+struct LnAdd {        // rows [B][h*w][D] fp32 added to the last Y*X tokens of every L
+  const float* add;   // (nullptr: plain LayerNorm)
+  int L, h, w;
+  float sy, sx;       // (float)h / Y, (float)w / X
+};
 template <int K, bool PADDED>
 __global__ __launch_bounds__(256) void k_layernorm_f32(
     const float* __restrict__ x, const float* __restrict__ gamma,
     const float* __restrict__ beta, void* __restrict__ out, int T, float eps, int Y,
-    int X) {
+    int X, LnAdd ad) {
   constexpr int D = 128 * K;
   const int l = threadIdx.x & 31;
   const int64_t row = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);
   if (row >= T) return;  // a whole half-wave leaves; the shuffles below stay inside one
   const float4* p = reinterpret_cast<const float4*>(x + row * D);
+  // optional: + the nearest-resized row of a coarser map (the HSA block's "offset")
+  const float4* pa = nullptr;
+  if (ad.add != nullptr) {
+    const int t = (int)(row % ad.L) - (ad.L - Y * X);   // position on the Y x X token map
+    if (t >= 0) {
+      const int py = t / X, px = t - py * X;
+      // F.interpolate(mode='nearest'): src = min(floor(dst * (in / out)), in - 1), in fp32
+      const int iy = min((int)floorf(py * ad.sy), ad.h - 1);
+      const int ix = min((int)floorf(px * ad.sx), ad.w - 1);
+      pa = reinterpret_cast<const float4*>(
+          ad.add + (((row / ad.L) * ad.h + iy) * ad.w + ix) * (int64_t)D);
+    }
+  }
   float4 v[K];
   float s = 0.f;
 #pragma unroll
   for (int k = 0; k < K; ++k) {
     v[k] = p[l + 32 * k];
+    if (pa != nullptr) {
+      const float4 a = pa[l + 32 * k];
+      v[k].x += a.x; v[k].y += a.y; v[k].z += a.z; v[k].w += a.w;
+    }
     s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
   }
 #pragma unroll
@@ -1234,7 +1256,7 @@ __global__ __launch_bounds__(256) void k_layernorm_f32(
 
 static int layernorm_f32_impl(const float* x, const float* gamma, const float* beta,
                               void* out, int T, int d, float eps, int Y, int X,
-                              bool padded, void* stream) {
+                              bool padded, void* stream, LnAdd ad = LnAdd{}) {
   if (!x || !gamma || !beta || !out || T <= 0 || d <= 0 || d % 128 != 0 || d > 1024)
     return VEON_ERR_BAD_ARG;
   if (!al16(x) || !al16(gamma) || !al16(beta) || !al16(out)) return VEON_ERR_BAD_ARG;
@@ -1245,10 +1267,10 @@ static int layernorm_f32_impl(const float* x, const float* gamma, const float* b
   do {                                                                          \
     if (padded)                                                                 \
       hipLaunchKernelGGL((k_layernorm_f32<K, true>), grid, dim3(256), 0, s, x, gamma,  \
-                         beta, out, T, eps, Y, X);                              \
+                         beta, out, T, eps, Y, X, ad);                          \
     else                                                                        \
       hipLaunchKernelGGL((k_layernorm_f32<K, false>), grid, dim3(256), 0, s, x, gamma, \
-                         beta, out, T, eps, 1, 1);                              \
+                         beta, out, T, eps, Y, X, ad);                          \
   } while (0)
   switch (d / 128) {
     case 1: VEON_LN32(1); break;
@@ -1267,6 +1289,23 @@ static int layernorm_f32_impl(const float* x, const float* gamma, const float* b
 extern "C" int veon_layernorm_f32(const float* x, const float* gamma, const float* beta,
                                   float* out, int T, int d, float eps, void* stream) {
   return layernorm_f32_impl(x, gamma, beta, out, T, d, eps, 1, 1, false, stream);
+}
+
+extern "C" int veon_layernorm_f32_add_nearest(const float* x, const float* add,
+                                              const float* gamma, const float* beta,
+                                              float* out, int B, int L, int d, int Y, int X,
+                                              int h, int w, float eps, void* stream) {
+  if (!add || B <= 0 || L <= 0 || Y <= 0 || X <= 0 || h <= 0 || w <= 0 ||
+      (int64_t)Y * X > L || (int64_t)B * L > 0x7fffffffLL || !al16(add))
+    return VEON_ERR_BAD_ARG;
+  LnAdd ad;
+  ad.add = add;
+  ad.L = L;
+  ad.h = h;
+  ad.w = w;
+  ad.sy = (float)h / (float)Y;
+  ad.sx = (float)w / (float)X;
+  return layernorm_f32_impl(x, gamma, beta, out, B * L, d, eps, Y, X, false, stream, ad);
 }
 
 extern "C" int veon_layernorm_f32_to_padded(const float* x, const float* gamma,

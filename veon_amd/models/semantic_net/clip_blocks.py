@@ -181,7 +181,12 @@ def run_blocks(blocks, x_lnd, attn_masks=None, cache=None, keep=None):
             ws = vit_ops.block_workspace(N, L, D, w.packed.mlp_dim, s.device)
         vit_ops.block_forward_(s, w.packed, N, L, ws, m)
         if keep is None or i in keep or i == len(blocks) - 1:
-            outs.append(s.view(N, L, D).permute(1, 0, 2).contiguous())
+            # (L, N, D)-shaped VIEW of a batch-major snapshot (the stream itself after
+            # the last block): ClipRecHead._save's permute / reshape to an (N, C, h, w)
+            # map is then a view too (channels-last strides) -- one copy per tapped
+            # layer instead of two, none for the last
+            snap = s.view(N, L, D) if i == len(blocks) - 1 else s.view(N, L, D).clone()
+            outs.append(snap.permute(1, 0, 2))
         else:
             outs.append(None)
     return outs

@@ -216,6 +216,15 @@ class HighresSideAdaptorBlock(nn.Module):
         x = self.ff(x, offset_shape, residual=x, pre_ln=self.ln_3)
         if offset is not None:
             offset = self.neck_add(offset.reshape(B, C_clip, -1).permute(0, 2, 1))
+            if (native and x.is_cuda and not torch.is_grad_enabled()
+                    and isinstance(self.ln_4, nn.LayerNorm) and x.dtype == torch.float32
+                    and offset.dtype == torch.float32 and x.shape[-1] % 128 == 0
+                    and x.shape[-1] <= 1024
+                    and offset_shape[0] * offset_shape[1] <= x.shape[1]):
+                # nearest resize + add onto the last tokens + ln_4 in one pass
+                return vit_ops.layernorm_f32_add_nearest(
+                    x.contiguous(), offset.contiguous(), offset_shape, (h_ext, w_ext),
+                    self.ln_4.weight.detach(), self.ln_4.bias.detach(), self.ln_4.eps)
             offset = _interp(offset.permute(0, 2, 1).reshape(B, -1, h_ext, w_ext),
                              size=offset_shape)
             offset = offset.reshape(B, offset.shape[1], -1).permute(0, 2, 1)
@@ -379,6 +388,8 @@ class HighresSideAdaptorNetwork(nn.Module):
         h, w = clip_features[1].shape[2], clip_features[1].shape[3]
         for layer_id, blk in enumerate(self.hsa_net_body):
             ca_id, add_id = self.cr_map[layer_id]
-            x = blk(x, None, clip_features[ca_id].contiguous(), None,
-                    clip_features[add_id].contiguous() if blk.use_add else None, (H, W))
+            # (the cross-attention source is read for its shape only; the add source is
+            # flattened to token rows by the block -- neither needs an NCHW copy)
+            x = blk(x, None, clip_features[ca_id], None,
+                    clip_features[add_id] if blk.use_add else None, (H, W))
         return self.rear_block(x, (H, W), (h, w))

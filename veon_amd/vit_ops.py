@@ -96,6 +96,24 @@ def layernorm_f32(x, weight, bias, eps=1e-5):
     return out
 
 
+def layernorm_f32_add_nearest(x, add, map_shape, add_shape, weight, bias, eps=1e-5):
+    """LayerNorm(x + offset): x fp32 [B, L, d]; ``add`` fp32 [B, h*w, d] is resized
+    (nearest, F.interpolate's default) from ``add_shape`` = (h, w) to ``map_shape`` =
+    (Y, X) and added to the last Y*X tokens of every sample."""
+    dev = _dev(x, add, weight, bias)
+    B, L, d = x.shape
+    (Y, X), (h, w) = map_shape, add_shape
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    assert add.dtype == torch.float32 and add.is_contiguous() and add.shape == (B, h * w, d)
+    out = torch.empty_like(x)
+    with _lib.on_device(dev):
+        st = _lib.lib().veon_layernorm_f32_add_nearest(
+            _lib.ptr(x), _lib.ptr(add), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(out),
+            B, L, d, Y, X, h, w, float(eps), _lib.stream_ptr(dev))
+    _lib.check(st, 'veon_layernorm_f32_add_nearest')
+    return out
+
+
 def linear(a, w, bias=None, epilogue=EPI_BF16, out=None, gamma=None):
     """a bf16 [M,K], w bf16 [N,K] (nn.Linear layout) -> bf16 [M,N].  ``gamma``
     (fp32 [N]) is the per-feature scale of the EPI_AFFINE* epilogues."""
