@@ -619,6 +619,18 @@ int veon_conv2d_k3_bf16(const void *in_padded, const void *w_bf16,
                         const float *scale, const float *shift,
                         const void *resid_padded, void *out_padded, int B, int Y,
                         int X, int Cin, int Cout, int relu, void *stream);
+/* The same with two optional extras of the epilogue (NULL = absent): a SECOND residual
+ * image resid2 (added before the activation) and a second output out_relu that receives
+ * relu(result) (not `out_padded` itself).  FeatureFusionBlock (util/blocks.py:86-148)
+ * computes  x0 + RCU1(x1)  and every ResidualConvUnit starts with relu(input) (:49-83):
+ * with these, conv2 of RCU1 writes x0 + conv + x1 and its ReLU in one pass, and the
+ * layer*_rn convolutions write the ReLU of their output next to it -- no elementwise
+ * add_ / clamp_min passes over the images. */
+int veon_conv2d_k3_bf16_ex(const void *in_padded, const void *w_bf16, const float *scale,
+                           const float *shift, const void *resid_padded,
+                           const void *resid2_padded, void *out_padded,
+                           void *out_relu_padded, int B, int Y, int X, int Cin, int Cout,
+                           int relu, void *stream);
 /* The same with stride 2 (Conv2d(k = 3, stride = 2, padding = 1): DPTHead.resize_layers[3],
  * depth_anything/dpt.py:69-72): in = padded image (B, Cin, Yin, Xin), out = padded image
  * (B, Cout, ceil(Yin/2), ceil(Xin/2)); only the needed output pixels are computed (the

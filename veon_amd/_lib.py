@@ -95,6 +95,7 @@ _SIGNATURES = {
     'veon_conv_tile_choice': (_ci, [_ci] * 8),
     'veon_conv3d_k3_bf16': (_ci, [_vp] * 6 + [_ci] * 7 + [_vp]),
     'veon_conv2d_k3_bf16': (_ci, [_vp] * 6 + [_ci] * 6 + [_vp]),
+    'veon_conv2d_k3_bf16_ex': (_ci, [_vp] * 8 + [_ci] * 6 + [_vp]),
     'veon_conv2d_k3s2_bf16': (_ci, [_vp] * 6 + [_ci] * 6 + [_vp]),
     'veon_image_resize_bilinear': (_ci, [_vp, _vp] + [_ci] * 6 + [_vp]),
     'veon_image_dot': (_ci, [_vp, _vp, _cf, _vp] + [_ci] * 5 + [_vp]),

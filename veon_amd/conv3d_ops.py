@@ -241,10 +241,11 @@ _ACT = {None: 0, 'none': 0, 'relu': 1, 'gelu': 2}
 
 
 def conv2d_k3(img, w_packed, scale=None, shift=None, resid=None, relu=False,
-              out=None, act=None):
+              out=None, act=None, resid2=None, out_relu=None):
     """3x3 stride-1 pad-1 convolution on a PaddedImage with the fused epilogue
-    ``act(conv*scale + shift + resid?)`` -> PaddedImage; ``act`` in none / relu /
-    gelu (``relu=True`` is shorthand for act='relu')."""
+    ``act(conv*scale + shift + resid? + resid2?)`` -> PaddedImage; ``act`` in none /
+    relu / gelu (``relu=True`` is shorthand for act='relu').  ``out_relu``: a second
+    PaddedImage that receives relu(result)."""
     dev = _lib.require_device(img.storage, w_packed)
     B, Cin, Y, X = img.shape
     Cout = w_packed.shape[0]
@@ -254,13 +255,23 @@ def conv2d_k3(img, w_packed, scale=None, shift=None, resid=None, relu=False,
     if out is None:
         out = PaddedImage(B, Cout, Y, X, dev)
     assert out.shape == (B, Cout, Y, X) and out is not img
-    if resid is not None:
-        assert resid.shape == out.shape
+    for extra in (resid, resid2, out_relu):
+        assert extra is None or extra.shape == out.shape
+    assert out_relu is None or (out_relu is not out and out_relu is not img)
+
+    def rows(p):
+        return _lib.ptr(None if p is None else p.rows)
     with torch.cuda.device(dev):
-        st = _lib.lib().veon_conv2d_k3_bf16(
-            _lib.ptr(img.rows), _lib.ptr(w_packed), _lib.ptr(scale), _lib.ptr(shift),
-            _lib.ptr(None if resid is None else resid.rows), _lib.ptr(out.rows),
-            B, Y, X, Cin, Cout, 1 if relu else _ACT[act], _lib.stream_ptr(dev))
+        if resid2 is None and out_relu is None:
+            st = _lib.lib().veon_conv2d_k3_bf16(
+                _lib.ptr(img.rows), _lib.ptr(w_packed), _lib.ptr(scale), _lib.ptr(shift),
+                rows(resid), _lib.ptr(out.rows),
+                B, Y, X, Cin, Cout, 1 if relu else _ACT[act], _lib.stream_ptr(dev))
+        else:
+            st = _lib.lib().veon_conv2d_k3_bf16_ex(
+                _lib.ptr(img.rows), _lib.ptr(w_packed), _lib.ptr(scale), _lib.ptr(shift),
+                rows(resid), rows(resid2), _lib.ptr(out.rows), rows(out_relu),
+                B, Y, X, Cin, Cout, 1 if relu else _ACT[act], _lib.stream_ptr(dev))
     _lib.check(st, 'veon_conv2d_k3_bf16')
     return out
 

@@ -29,6 +29,15 @@ namespace {
 
 constexpr int CBK = 64;
 
+// Optional extras of the epilogue (both null in the 3-D body): a SECOND residual image
+// added before the activation, and a second output that receives relu(result) -- the
+// DPT fusion blocks' "x0 + RCU1(x1)" and the ReLU every ResidualConvUnit applies to its
+// input (util/blocks.py:49-83), which otherwise cost an elementwise pass each.
+struct ConvExtra {
+  const bf16_t* resid2;
+  bf16_t* out_relu;
+};
+
 // Tile = (WM*16*MT) voxels x (64*WN) features, WM x WN waves of (16*MT) x 64 each.
 template <int WM, int WN, int MT, int ACT, bool RESID>
 __global__ __launch_bounds__(64 * WM * WN) void k_conv3d_k3(
@@ -36,7 +45,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv3d_k3(
     const float* __restrict__ scale, const float* __restrict__ shift,
     const bf16_t* __restrict__ resid, bf16_t* __restrict__ out, int planes,
     int Zp, int Yp, int Xp, int Cin, int Cout, int kd, int abl, int stride, int Ypi,
-    int Xpi) {
+    int Xpi, ConvExtra ex) {
   // stride 2 (kd == 1 only): planes / Yp / Xp describe the OUTPUT grid, Ypi / Xpi the
   // padded input image; output pixel (y, x) reads the 3x3 neighbourhood of input
   // pixel (2y, 2x).  The DMA source of a tile row is a per-lane pointer anyway, so the
@@ -226,6 +235,12 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv3d_k3(
 #pragma unroll
         for (int k = 0; k < 8; ++k) v[k] += bf2f((bf16_t)r8[k]);
       }
+      if (ex.resid2 != nullptr) {
+        const bf16x8 r8 =
+            *reinterpret_cast<const bf16x8*>(ex.resid2 + (int64_t)m * Cout + n);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] += bf2f((bf16_t)r8[k]);
+      }
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         if (ACT == 1) v[k] = fmaxf(v[k], 0.f);
@@ -235,6 +250,14 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv3d_k3(
       const uint4 o = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]),
                        pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])};
       *reinterpret_cast<uint4*>(out + (int64_t)m * Cout + n) = o;
+      if (ex.out_relu != nullptr) {
+        // relu of the ROUNDED result: what a separate pass over `out` would produce
+        const uint4 q = {pack_bf16(fmaxf(v[0], 0.f), fmaxf(v[1], 0.f)),
+                         pack_bf16(fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)),
+                         pack_bf16(fmaxf(v[4], 0.f), fmaxf(v[5], 0.f)),
+                         pack_bf16(fmaxf(v[6], 0.f), fmaxf(v[7], 0.f))};
+        *reinterpret_cast<uint4*>(ex.out_relu + (int64_t)m * Cout + n) = q;
+      }
     }
   }
 }
@@ -254,7 +277,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv3d_k3_ax(
     const bf16_t* __restrict__ in, const bf16_t* __restrict__ W,
     const float* __restrict__ scale, const float* __restrict__ shift,
     const bf16_t* __restrict__ resid, bf16_t* __restrict__ out, int planes,
-    int Zp, int Yp, int Xp, int Cin, int Cout, int kd) {
+    int Zp, int Yp, int Xp, int Cin, int Cout, int kd, ConvExtra ex) {
   constexpr int BM = WM * 16 * MT;
   constexpr int CBN = 64 * WN;
   constexpr int NW = WM * WN;              // waves
@@ -457,6 +480,12 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv3d_k3_ax(
 #pragma unroll
         for (int k = 0; k < 8; ++k) v[k] += bf2f((bf16_t)r8[k]);
       }
+      if (ex.resid2 != nullptr) {
+        const bf16x8 r8 =
+            *reinterpret_cast<const bf16x8*>(ex.resid2 + (int64_t)m * Cout + n);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] += bf2f((bf16_t)r8[k]);
+      }
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         if (ACT == 1) v[k] = fmaxf(v[k], 0.f);
@@ -466,6 +495,14 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv3d_k3_ax(
       const uint4 o = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]),
                        pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])};
       *reinterpret_cast<uint4*>(out + (int64_t)m * Cout + n) = o;
+      if (ex.out_relu != nullptr) {
+        // relu of the ROUNDED result: what a separate pass over `out` would produce
+        const uint4 q = {pack_bf16(fmaxf(v[0], 0.f), fmaxf(v[1], 0.f)),
+                         pack_bf16(fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)),
+                         pack_bf16(fmaxf(v[4], 0.f), fmaxf(v[5], 0.f)),
+                         pack_bf16(fmaxf(v[6], 0.f), fmaxf(v[7], 0.f))};
+        *reinterpret_cast<uint4*>(ex.out_relu + (int64_t)m * Cout + n) = q;
+      }
     }
   }
 }
@@ -855,8 +892,12 @@ static int conv_k3_impl(int kd, const void* in_padded, const void* w_bf16,
                         const float* scale, const float* shift,
                         const void* resid_padded, void* out_padded, int B, int Z,
                         int Y, int X, int Cin, int Cout, int relu, void* stream,
-                        int stride = 1, int Yin = 0, int Xin = 0) {
+                        int stride = 1, int Yin = 0, int Xin = 0,
+                        ConvExtra ex = ConvExtra{nullptr, nullptr}) {
   // Y, X: the OUTPUT grid; Yin, Xin: the input image of a strided 2-D conv
+  if ((ex.resid2 && !al16(ex.resid2)) || (ex.out_relu && !al16(ex.out_relu)) ||
+      (ex.out_relu && ex.out_relu == out_padded))
+    return VEON_ERR_BAD_ARG;
   if (stride == 1) { Yin = Y; Xin = X; }
   if (stride < 1 || stride > 2 || (stride == 2 && kd != 1) || Yin <= 0 || Xin <= 0)
     return VEON_ERR_BAD_ARG;
@@ -896,7 +937,7 @@ static int conv_k3_impl(int kd, const void* in_padded, const void* w_bf16,
       if (attrx != hipSuccess) return VEON_ERR_LAUNCH;                         \
       hipLaunchKernelGGL((k_conv3d_k3_ax<WM, WN, MT, ACT, RESID>), grid,      \
                          dim3(64 * WM * WN), ldsx, s, I, Wt, scale, shift, R, O, \
-                         planes, Z + 2 * pz, Y + 2, X + 2, Cin, Cout, kd);     \
+                         planes, Z + 2 * pz, Y + 2, X + 2, Cin, Cout, kd, ex); \
       break;                                                                   \
     }                                                                          \
     constexpr int lds =                                                        \
@@ -908,7 +949,7 @@ static int conv_k3_impl(int kd, const void* in_padded, const void* w_bf16,
     hipLaunchKernelGGL((k_conv3d_k3<WM, WN, MT, ACT, RESID>), grid,           \
                        dim3(64 * WM * WN), lds, s, I, Wt, scale, shift, R, O,  \
                        planes, Z + 2 * pz, Y + 2, X + 2, Cin, Cout, kd,        \
-                       g_conv_abl, stride, Yin + 2, Xin + 2);                  \
+                       g_conv_abl, stride, Yin + 2, Xin + 2, ex);              \
   } while (0)
 #define VEON_TILE_IS(a, b, c) (wm == a && wn == b && mt == c)
 #define VEON_LAUNCH_CONV_T(ACT, RESID)                                        \
@@ -966,6 +1007,18 @@ int veon_conv2d_k3_bf16(const void* in_padded, const void* w_bf16,
                         int X, int Cin, int Cout, int relu, void* stream) {
   return conv_k3_impl(1, in_padded, w_bf16, scale, shift, resid_padded, out_padded,
                       B, 1, Y, X, Cin, Cout, relu, stream);
+}
+
+int veon_conv2d_k3_bf16_ex(const void* in_padded, const void* w_bf16, const float* scale,
+                           const float* shift, const void* resid_padded,
+                           const void* resid2_padded, void* out_padded,
+                           void* out_relu_padded, int B, int Y, int X, int Cin, int Cout,
+                           int relu, void* stream) {
+  ConvExtra ex;
+  ex.resid2 = static_cast<const bf16_t*>(resid2_padded);
+  ex.out_relu = static_cast<bf16_t*>(out_relu_padded);
+  return conv_k3_impl(1, in_padded, w_bf16, scale, shift, resid_padded, out_padded, B, 1,
+                      Y, X, Cin, Cout, relu, stream, 1, 0, 0, ex);
 }
 
 int veon_conv2d_k3s2_bf16(const void* in_padded, const void* w_bf16, const float* scale,

@@ -44,9 +44,10 @@ class _HipConv:
                                                     img.shape[2], img.shape[3], img.device)
         return self.bufs[key]
 
-    def __call__(self, img, relu=False, resid=None, tag=0):
+    def __call__(self, img, relu=False, resid=None, tag=0, resid2=None, out_relu=None):
         return conv3d_ops.conv2d_k3(img, self.w, None, self.shift, resid=resid,
-                                    relu=relu, out=self.out_buf(img, tag))
+                                    relu=relu, out=self.out_buf(img, tag), resid2=resid2,
+                                    out_relu=out_relu)
 
 
 def _hip_cache(mod, name, conv):
@@ -77,13 +78,21 @@ class ResidualConvUnit(NativeCacheMixin, nn.Module):
             out = self.bn2(out)
         return out + x
 
-    def hip_forward(self, img, scratch):
-        """conv2(relu(conv1(relu(x)))) + x on a PaddedImage: ReLU of the input
-        is one elementwise pass (the zero halo stays zero), bias + ReLU and
-        bias + identity are the convs' epilogues."""
-        torch.clamp_min(img.rows, 0, out=scratch.rows)
-        u = _hip_cache(self, 'conv1', self.conv1)(scratch, relu=True, tag=1)
-        return _hip_cache(self, 'conv2', self.conv2)(u, resid=img, tag=2)
+    def hip_forward(self, img, scratch, plus=None, out_relu=None):
+        """conv2(relu(conv1(relu(x)))) + x on a PaddedImage (``plus``: + another image;
+        ``out_relu``: relu(result) written too): bias + ReLU and bias + identity (+ the
+        extras) are the convs' epilogues.  ReLU of the input: the producer left it in
+        ``img.relu_copy`` (a conv with ``out_relu``), else one elementwise pass here
+        (the zero halo stays zero)."""
+        relu_in = getattr(img, 'relu_copy', None)
+        if relu_in is None:
+            torch.clamp_min(img.rows, 0, out=scratch.rows)
+            relu_in = scratch
+        u = _hip_cache(self, 'conv1', self.conv1)(relu_in, relu=True, tag=1)
+        r = _hip_cache(self, 'conv2', self.conv2)(u, resid=img, tag=2, resid2=plus,
+                                                  out_relu=out_relu)
+        r.relu_copy = out_relu
+        return r
 
 
 class FeatureFusionBlock(NativeCacheMixin, nn.Module):
@@ -120,8 +129,10 @@ class FeatureFusionBlock(NativeCacheMixin, nn.Module):
         B, C, H, W = x0.shape
         scratch = self._buf('relu', B, C, H, W, x0.device)
         if x1 is not None:
-            r = self.resConfUnit1.hip_forward(x1, scratch)
-            x0.rows.add_(r.rows)
+            # x0 + RCU1(x1) and its ReLU (RCU2's input) out of RCU1.conv2's epilogue
+            x0 = self.resConfUnit1.hip_forward(x1, scratch, plus=x0,
+                                               out_relu=self._buf('relu2', B, C, H, W,
+                                                                  x0.device))
         y = self.resConfUnit2.hip_forward(x0, scratch)
         if '_hip_1x1' not in self.__dict__:
             oc = self.out_conv
@@ -299,8 +310,11 @@ class DPTHead(NativeCacheMixin, nn.Module):
                     img, lv['wc'], None, lv['bc'],
                     out=image(('s2', i), ocp, (patch_h + 1) // 2, (patch_w + 1) // 2))
             Y, X = img.shape[2:]
-            outs.append(conv3d_ops.conv2d_k3(img, lv['wr'], None, lv['br'],
-                                             out=image(('rn', i), lv['wr'].shape[0], Y, X)))
+            rn = conv3d_ops.conv2d_k3(img, lv['wr'], None, lv['br'],
+                                      out=image(('rn', i), lv['wr'].shape[0], Y, X),
+                                      out_relu=image(('rnr', i), lv['wr'].shape[0], Y, X))
+            rn.relu_copy = image(('rnr', i), lv['wr'].shape[0], Y, X)
+            outs.append(rn)
         return outs
 
     def hip_forward(self, taps, B, T, patch_h, patch_w):

@@ -136,7 +136,14 @@ class _HipClipWeights:
             self.act, q_log2=True)
 
 
-def run_blocks(blocks, x_lnd, attn_masks=None, cache=None, keep=None):
+def hip_blocks_ok(blocks, x, D):
+    """The condition of run_blocks' MFMA path."""
+    return (x.is_cuda and not torch.is_grad_enabled()
+            and not any(b.training for b in blocks)
+            and D % 64 == 0 and all(D // b.n_head == 64 for b in blocks))
+
+
+def run_blocks(blocks, x_lnd, attn_masks=None, cache=None, keep=None, stream=None):
     """Run ``blocks`` over x (L, N, D).  On a ROCm device in no-grad eval mode
     the MFMA kernels are used (one transpose in, one out); otherwise the torch
     blocks.  attn_masks: None or one additive mask per block, each
@@ -145,9 +152,7 @@ def run_blocks(blocks, x_lnd, attn_masks=None, cache=None, keep=None):
     (the last one always is); the native path leaves the others as None instead of
     copying the stream out after every block."""
     L, N, D = x_lnd.shape
-    hip = (x_lnd.is_cuda and not torch.is_grad_enabled()
-           and not any(b.training for b in blocks)
-           and D % 64 == 0 and all(D // b.n_head == 64 for b in blocks))
+    hip = hip_blocks_ok(blocks, x_lnd, D)
     outs = []
     if not hip:
         x = x_lnd
@@ -160,9 +165,16 @@ def run_blocks(blocks, x_lnd, attn_masks=None, cache=None, keep=None):
         return outs
     if cache is None:
         cache = {}
-    # private batch-major fp32 copy of the stream (the kernels update it in place)
-    s = torch.empty((N, L, D), dtype=torch.float32, device=x_lnd.device)
-    s.copy_(x_lnd.permute(1, 0, 2))
+    # private batch-major fp32 copy of the stream (the kernels update it in place);
+    # ``stream``: the caller already holds one ((N, L, D) fp32, its to overwrite) of
+    # which x_lnd is the (L, N, D) view
+    if stream is not None:
+        assert stream.shape == (N, L, D) and stream.dtype == torch.float32 \
+            and stream.is_contiguous()
+        s = stream
+    else:
+        s = torch.empty((N, L, D), dtype=torch.float32, device=x_lnd.device)
+        s.copy_(x_lnd.permute(1, 0, 2))
     s = s.view(N * L, D)
     ws = None
     for i, blk in enumerate(blocks):
@@ -268,14 +280,47 @@ class ClipVisualTrunk(nn.Module):
         x = torch.cat([cls, x], dim=1) + self._pos_embed(h, w).to(x.dtype)
         return self.ln_pre(x).permute(1, 0, 2), (h, w)     # LND
 
+    def _native_stream(self, x):
+        """``tokens`` at inference as four launches: the position rows (+ the class
+        embedding in row 0) repeated into a fresh fp32 stream, the patches gathered as
+        bf16 GEMM rows (class-token slots zero), one MFMA GEMM accumulating conv-weight x
+        patch onto the stream, ln_pre fp32 -> fp32.  -> ((N, L, D) fp32, (h, w)).
+        (The patch product runs on bf16 operands here; everything after it does anyway.)"""
+        N, C, H, W = x.shape
+        p, D = self.patch_size, self.conv1.out_channels
+        h, w = H // p, W // p
+        key = ('tok', h, w, x.device)
+        if key not in self._pos_cache:
+            k = C * p * p
+            kpad = (k + 63) // 64 * 64
+            wp = torch.zeros(D, kpad, device=x.device)
+            wp[:, :k] = self.conv1.weight.detach().float().view(D, k)
+            base = self._pos_embed(h, w).detach().float().clone()
+            base[0] += self.class_embedding.detach().float()
+            self._pos_cache[key] = (vit_ops.to_bf16(wp), base.contiguous(), kpad)
+        wp, base, kpad = self._pos_cache[key]
+        s = base.repeat(N, 1)           # always a fresh buffer: the blocks run in place on it
+        assert s.data_ptr() != base.data_ptr()
+        vit_ops.linear_residual_(s, vit_ops.patchify(x, p, 1, kpad), wp, None)
+        s = vit_ops.layernorm_f32(s, self.ln_pre.weight.detach(), self.ln_pre.bias.detach(),
+                                  self.ln_pre.eps)
+        return s.view(N, 1 + h * w, D), (h, w)
+
     def forward(self, x, last_layer_idx=-1, attn_masks=None, taps=None):
         """-> (list of per-block token tensors (L,N,D), (h, w)); entry 0 = the tokens
         after ``ln_pre``, entry i = the output of block i.  ``taps``: the entries the
         caller reads (None = all); untapped entries may come back as None."""
-        t, hw = self.tokens(x)
         blocks = list(self.resblocks if last_layer_idx == -1
                       else self.resblocks[:last_layer_idx])
         keep = None if taps is None else {i - 1 for i in taps if i >= 1}
+        D = self.conv1.out_channels
+        if (hip_blocks_ok(blocks, x, D) and not self.training and D % 128 == 0
+                and D <= 1024 and x.dtype == torch.float32 and blocks):
+            s, hw = self._native_stream(x)
+            t = (s.clone() if taps is None or 0 in taps else s).permute(1, 0, 2)
+            return [t] + run_blocks(blocks, t, attn_masks, self._hip_cache, keep,
+                                    stream=s), hw
+        t, hw = self.tokens(x)
         return [t] + run_blocks(blocks, t, attn_masks, self._hip_cache, keep), hw
 
 
@@ -428,8 +473,12 @@ class ClipRecHead(nn.Module):
                         # saved map of the block before the middle carries the
                         # second offset too
                         self._save(clip_outputs, a + k0, x, hw)
+            # (biases that already carry the class token's zero row / column --
+            # AttnManipulateBlock.pad_class_token -- pass through)
+            L1 = x.shape[0]
             masks = None if attns is None else \
-                [self.build_attn_bias(attns[t]) for t in range(a, b)]
+                [attns[t].reshape(-1, L1, L1) if attns[t].shape[-1] == L1
+                 else self.build_attn_bias(attns[t]) for t in range(a, b)]
             keep = None if keep_layers is None else \
                 {t - a for t in range(a, b) if t + k0 + 1 in keep_layers}
             outs = run_blocks(list(self.resblocks)[a:b], x, masks, self._hip_cache, keep)

@@ -252,6 +252,10 @@ class AttnManipulateBlock(nn.Module):
         self.head_supp = FeedForward(mlp_dim, mlp_dim, supp_dim)
         self.ln_3 = nn.LayerNorm(dim)
         self.ln_4 = nn.LayerNorm(mlp_dim)
+        # veon_amd extension (inference only): emit the attention biases already
+        # bordered for the class token, (layers, B, heads, hw + 1, hw + 1);
+        # ClipRecHead.build_attn_bias passes such matrices through
+        self.pad_class_token = False
 
     def forward(self, x, side_shape=(1, 1), new_shape=(1, 1)):
         native = self.ff.conv_dtype == _half.dtype() and not self.training
@@ -272,7 +276,23 @@ class AttnManipulateBlock(nn.Module):
         # einsum writes it with the layer / head axes innermost -- 36 floats apart
         # -- and every consumer then copies it)
         q = attns.permute(2, 0, 3, 1, 4)                       # (a, b, h, m, d)
-        attns = torch.matmul(q, q.transpose(-1, -2))
+        if self.pad_class_token and not torch.is_grad_enabled():
+            # Gram matrices of the embeddings with a ZERO row in front: the zero row /
+            # column of the class token that RecWithAttnbiasHead's bias builder
+            # (clip_utils/visual.py:287-292) adds afterwards comes out of the same batched
+            # matmul, instead of a zero fill and a strided copy of every (L+1)^2 matrix
+            key = (tuple(q.shape), q.dtype, q.device)
+            pad = self.__dict__.get('_qpad')
+            if pad is None or pad[0] != key:
+                a_, b_, h_, m_, d_ = q.shape
+                pad = (key, torch.zeros(a_, b_, h_, m_ + 1, d_, dtype=q.dtype,
+                                        device=q.device))
+                self.__dict__['_qpad'] = pad
+            qp = pad[1]
+            qp[..., 1:, :].copy_(q)
+            attns = torch.matmul(qp, qp.transpose(-1, -2))
+        else:
+            attns = torch.matmul(q, q.transpose(-1, -2))
         supp = supp.permute(0, 2, 1).reshape(B, -1, H, W)
         return None, attns, supp
 

@@ -89,6 +89,9 @@ class VeonOccupancyPath(nn.Module):
             dim=hsa_dim, clip_dim=clip_width, mlp_dim=hsa_dim, input_size=input_size,
             fusion_map=hsa_fusion_map, manip_supp_dim=hsa_dim, num_heads=clip_heads,
             manip_attn_layers=max(clip_layers - clip_first_tail, 1))
+        # its attention biases feed ClipRecHead.update_remaining_clip_feats only: let them
+        # come out already bordered for the class token (inference)
+        self.hsa.rear_block.pad_class_token = True
         self.view_transformer = build_neck(dict(
             type='LSSViewTransformerRaw', grid_config=grid_config, input_size=input_size,
             out_channels=embed_dim, collapse_z=False, ds_feat=[2, 2, 2]))
