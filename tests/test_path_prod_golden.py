@@ -92,10 +92,13 @@ def test_path_wiring_at_production_widths_on_cpu():
 # measured on MI355X (printed by the test): relative L2 / max |diff| over the logit range
 #   bf16  sem 2.07e-2 / 2.43e-2, bin 2.13e-2 / 3.75e-2, arg-max agreement 0.9937,
 #         metric depth max |diff| 0.61 m of 18..66 m
-#   fp16  sem 2.07e-3 / 1.77e-3, bin 2.16e-3 / 3.00e-3, agreement 1.0000, depth 0.068 m
+#   fp16  sem 2.24e-3 / 2.24e-3, bin 2.34e-3 / 5.14e-3, agreement 1.0000, depth 0.062 m
+#         (2.07e-3 / 1.77e-3 and 2.16e-3 / 3.00e-3 while CLIP's patch embedding was an fp32
+#         torch matmul; it now runs on half-precision operands like every other GEMM of the
+#         trunk -- ClipVisualTrunk._native_stream)
 # the bounds are those numbers + 50 %
 TOL = {'bf16': dict(rel=3.2e-2, mx=5.6e-2, agree=0.985, depth=0.92),
-       'fp16': dict(rel=3.3e-3, mx=4.5e-3, agree=0.995, depth=0.10)}
+       'fp16': dict(rel=3.5e-3, mx=7.7e-3, agree=0.995, depth=0.10)}
 
 
 @pytest.mark.gpu

@@ -179,7 +179,9 @@ enum { EPI_BF16 = 0, EPI_GELU = 1, EPI_QUICKGELU = 2, EPI_RESID = 3,
        EPI_AFFINE_SIGM = 6 };  // sigmoid(affine) - 0.5 = tanh(x/2)/2 (PredHead3DSem)
 
 __device__ __forceinline__ float quick_gelu(float x) {
-  return x / (1.f + __expf(-1.702f * x));
+  // x * sigmoid(1.702 x); v_exp + v_rcp (1 ulp each, the output is bf16) instead of
+  // __expf and an IEEE division (ten more instructions per element)
+  return x * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.702f * 1.4426950408889634f * x));
 }
 
 
