@@ -28,6 +28,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ... import vit_ops
+from .resize import interpolate
 
 
 class QuickGELU(nn.Module):
@@ -390,8 +391,8 @@ class ClipRecHead(nn.Module):
             n, num_head, num_sos, h, w = ab.shape
             ab = ab.reshape(n, num_head * num_sos, h, w)
             if self.downsample_method in ('bicubic', 'bilinear', 'nearest'):
-                ab = F.interpolate(ab, size=target_shape, mode=self.downsample_method,
-                                   align_corners=False)
+                ab = interpolate(ab, size=target_shape, mode=self.downsample_method,
+                                 align_corners=False)
             elif self.downsample_method == 'avg':
                 ab = F.adaptive_avg_pool2d(ab, output_size=target_shape)
             else:

@@ -27,12 +27,7 @@ from .._native_cache import NativeCacheMixin
 from ... import half as _half
 
 
-def _interp(x, **kw):
-    """F.interpolate; on a GPU in channels-last (same values, and torch's NCHW
-    kernels are very slow for many-channel, small maps)."""
-    if x.is_cuda:
-        x = x.contiguous(memory_format=torch.channels_last)
-    return F.interpolate(x, **kw)
+from .resize import interpolate as _interp
 
 
 def _ln(mod, x, native):

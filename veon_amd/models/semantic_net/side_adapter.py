@@ -31,6 +31,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .resize import interpolate
+
 from .fusion_layers import LayerNorm
 
 
@@ -59,8 +61,8 @@ class AddFusion(nn.Module):
                                         nn.Conv2d(in_channels, out_channels, kernel_size=1))
 
     def forward(self, x, y, spatial_shape):
-        y = F.interpolate(self.input_proj(y.contiguous()), size=spatial_shape,
-                          mode='bilinear', align_corners=False)
+        y = interpolate(self.input_proj(y.contiguous()), size=spatial_shape,
+                        mode='bilinear', align_corners=False)
         return x + y.permute(0, 2, 3, 1).reshape(x.shape)
 
 
@@ -321,9 +323,20 @@ class RegionwiseSideAdapterNetwork(nn.Module):
         pos_embed = vit.pos_embed
         ori_h, ori_w = vit.patch_embed.grid_size
         if pos_embed.shape[1] != L:
-            pos_embed = F.interpolate(
-                pos_embed.reshape(1, ori_h, ori_w, -1).permute(0, 3, 1, 2), size=[h, w],
-                mode='bicubic', align_corners=False).flatten(2).permute(0, 2, 1)
+            # (the resize costs more than a block: cached at inference, like CLIP's)
+            inference = not (self.training or torch.is_grad_enabled())
+            key = (h, w, pos_embed.device, pos_embed.dtype, pos_embed._version,
+                   pos_embed.data_ptr())
+            cache = self.__dict__.setdefault('_pos_resized', {})
+            if inference and key in cache:
+                pos_embed = cache[key]
+            else:
+                pos_embed = F.interpolate(
+                    pos_embed.reshape(1, ori_h, ori_w, -1).permute(0, 3, 1, 2), size=[h, w],
+                    mode='bicubic', align_corners=False).flatten(2).permute(0, 2, 1)
+                if inference:
+                    cache.clear()
+                    cache[key] = pos_embed.detach()
         pos_embed = torch.cat(
             [self.query_pos_embed.expand(pos_embed.shape[0], -1, -1), pos_embed], dim=1)
         x = torch.cat([self.query_embed.expand(x.shape[0], -1, -1), x], dim=1)  # B, Q+L, C
@@ -361,8 +374,8 @@ class RegionwiseSideAdapterNetwork(nn.Module):
             blk.forward_(s, B, T)
             if i in self.fusion_map:            # AddFusion onto the patch tokens, in place
                 layer = self.fusion_layers['layer_%d' % i]
-                y = F.interpolate(layer.input_proj(clip_features[self.fusion_map[i]].contiguous()),
-                                  size=(h, w), mode='bilinear', align_corners=False)
+                y = interpolate(layer.input_proj(clip_features[self.fusion_map[i]].contiguous()),
+                                size=(h, w), mode='bilinear', align_corners=False)
                 xs[:, -L:] += y.permute(0, 2, 3, 1).reshape(B, L, d)
             # (reshape alone would be a VIEW of the stream the next block overwrites)
             grid = xs[:, -L:].permute(0, 2, 1).reshape(B, d, h, w).contiguous()
