@@ -419,14 +419,15 @@ class ClipRecHead(nn.Module):
         else:
             sos = self.sos_token.expand(-1, n, -1) + cls_token
         biases = self._build_attn_biases(attn_bias, (h, w))
-        last = len(self.resblocks) - 1
-        for i, blk in enumerate(self.resblocks):
-            sos = cross_attn_layer(blk, sos, x[1:], biases[i])
-            if clip_outputs is None and i < last:
-                x = blk(x)
-            elif clip_outputs is not None:
-                x = blk(x)
-                self._save(clip_outputs, i + k0 + 1, x, (h, w))
+        blocks = list(self.resblocks)
+        # the patch tokens run through the plain blocks (the last one only when its
+        # output is saved): all at once, on the MFMA kernels where run_blocks can
+        run = blocks if clip_outputs is not None else blocks[:-1]
+        xs = [x] + (run_blocks(run, x, None, self._hip_cache) if run else [])
+        for i, blk in enumerate(blocks):
+            sos = cross_attn_layer(blk, sos, xs[i][1:], biases[i])
+            if clip_outputs is not None:
+                self._save(clip_outputs, i + k0 + 1, xs[i + 1], (h, w))
         sos = self.ln_post(sos.permute(1, 0, 2))
         if self.proj is not None:
             sos = sos @ self.proj

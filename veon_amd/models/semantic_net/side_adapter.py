@@ -260,8 +260,20 @@ class MLPMaskDecoder(nn.Module):
         b, c, h, w = pix.shape
         mask_preds = torch.einsum('bqc,bchw->bqhw', query, pix)
         attn = self.attn_mlp(x).reshape(b, self.total_layers, self.total_heads, c, h, w)
-        attn_bias = torch.einsum('bqc,blnchw->blnqhw', query, attn)
-        attn_bias = self.bias_scaling(attn_bias[..., None]).squeeze(-1)
+        if torch.is_grad_enabled():
+            attn_bias = torch.einsum('bqc,blnchw->blnqhw', query, attn)
+        else:
+            # the same contraction as a batched matmul over (b, l, n): the einsum lowers
+            # to ONE skinny fp32 mm (0.3 ms at 6 x 12 heads x 100 queries x 16 x 44)
+            attn_bias = torch.matmul(query[:, None, None], attn.flatten(4)).reshape(
+                b, self.total_layers, self.total_heads, query.shape[1], h, w)
+        if isinstance(self.bias_scaling, nn.Linear) and not torch.is_grad_enabled():
+            # Linear(1, 1) over five million scalars: as the multiply-add it is (the
+            # K = 1 GEMM torch makes of it takes 0.34 ms)
+            attn_bias = attn_bias * self.bias_scaling.weight.view(()) + \
+                self.bias_scaling.bias.view(())
+        else:
+            attn_bias = self.bias_scaling(attn_bias[..., None]).squeeze(-1)
         return mask_preds, [a.squeeze(1) for a in attn_bias.chunk(self.total_layers, dim=1)]
 
 
