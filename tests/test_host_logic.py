@@ -359,3 +359,21 @@ def test_conv_tile_choice_rule():
     assert tile(1, 6, 1, 144, 400, 128, 64)[1] == 64             # 64-feature class
     assert tile(1, 6, 1, 72, 200, 128, 128) == (128, 128)        # large 128-feature conv
     assert lib.veon_conv_tile_choice(1, 6, 1, 9, 25, 100, 128, 1) == -1   # Cin % 64
+
+
+def test_no_low_half_op_sel_packed_f32_beside_mfma_in_the_vit_kernels():
+    """v_pk_*_f32 with an op_sel that feeds the LOW half from the HIGH dword read
+    its operand as 0.0 in lanes 48-63 when the same wave issues MFMAs (stand-alone
+    reproducer tools/ubench/pk_opsel_repro.hip); hipcc emits that form on its own from
+    scalar code.  The ISA of vit_block.hip (GEMM, attention: where it happened) must not
+    contain it in any kernel that has MFMAs.  (tools/check_pk_opsel.py checks every source
+    in both flavours; that takes minutes.)"""
+    import importlib.util
+    import shutil
+    if shutil.which('hipcc') is None:
+        pytest.skip('no hipcc')
+    spec = importlib.util.spec_from_file_location(
+        'check_pk_opsel', os.path.join(ROOT, 'tools', 'check_pk_opsel.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.offenders(only={'vit_block.hip'}) == {}

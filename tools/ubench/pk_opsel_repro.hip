@@ -1,0 +1,163 @@
+// Stand-alone probe for DESIGN 4b "A wrong result that came and went": does
+//   v_pk_add_f32 dst, a, b op_sel:[0,1] neg_lo:[0,1] neg_hi:[0,1]
+// (low half reads the HIGH dword of b) give a - b.hi in every lane when it runs beside
+// MFMA and transcendental traffic on a full chip?  Each wave keeps 32 (a.lo, a.hi) pairs
+// and one (d1, d0) pair, performs the packed subtract and the same subtract with scalar
+// v_sub_f32, and counts lanes where the two differ, per 16-lane row and per half.
+//   hipcc --offload-arch=gfx950 -O3 -o pk_opsel_repro pk_opsel_repro.hip && ./pk_opsel_repro [iters]
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+typedef float __attribute__((ext_vector_type(2))) f32x2;
+typedef float __attribute__((ext_vector_type(4))) f32x4;
+typedef __bf16 __attribute__((ext_vector_type(8))) bf16x8;
+
+template <int MODE, int TRAFFIC, int NOPS = 0>
+__global__ __launch_bounds__(256, 3) void k(const float* __restrict__ in, unsigned long long* bad,
+                                            float* sink, int iters) {
+  const int lane = threadIdx.x & 63;
+  const int row = lane >> 4;
+  f32x2 x[16];
+  f32x4 acc[4] = {};
+  bf16x8 fa, fb;
+  for (int e = 0; e < 8; ++e) { fa[e] = (__bf16)(0.01f * (lane + e)); fb[e] = (__bf16)(0.02f * (e + 1)); }
+  float tr = in[threadIdx.x] + 1.f;
+  unsigned long long nbad_lo = 0, nbad_hi = 0, nalt = 0;
+  float dprev = 0.f;
+  if ((TRAFFIC & 4) && ((threadIdx.x >> 6) & 1)) {
+    // "MFMA by the OTHER waves": the odd waves of the workgroup only feed the matrix core
+    // (they share SIMDs with even waves of other workgroups), the even waves only do the
+    // packed subtracts
+    for (int it = 0; it < iters * 24; ++it) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, acc[m], 0, 0, 0);
+    }
+    float s = 0.f;
+    for (int m = 0; m < 4; ++m) s += acc[m][0] + acc[m][3];
+    if (s == 12345.678f) sink[0] = s;
+    return;
+  }
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      x[i][0] = in[(threadIdx.x + 37 * i + it) & 4095];
+      x[i][1] = in[(threadIdx.x + 53 * i + 7 * it) & 4095];
+    }
+    const float d0_prev = it ? dprev : 0.f;
+    f32x2 dpair;                       // (d1, d0): the packed op reads d0 = the HIGH dword
+    dpair[0] = in[(blockIdx.x + it) & 4095];
+    dpair[1] = in[(blockIdx.x * 3 + it + 11) & 4095] + (float)(lane & 15);
+    asm volatile("" : "+v"(dpair));
+    dprev = dpair[1];
+    // traffic beside it: MFMAs (TRAFFIC & 1) and transcendentals (TRAFFIC & 2)
+    if (TRAFFIC & 1) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, acc[m], 0, 0, 0);
+    }
+    if (TRAFFIC & 2) tr = __builtin_amdgcn_exp2f(tr * 0.001f) + 1.f;
+    f32x2 want[16], got[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      float lo, hi;
+      asm volatile("v_sub_f32 %0, %1, %2" : "=v"(lo) : "v"(x[i][0]), "v"(dpair[MODE == 2 ? 0 : 1]));
+      asm volatile("v_sub_f32 %0, %1, %2" : "=v"(hi) : "v"(x[i][1]), "v"(dpair[1]));
+      want[i][0] = lo; want[i][1] = hi;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      if (MODE == 1)
+        asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]"
+                     : "=v"(got[i]) : "v"(x[i]), "v"(dpair));
+      else if (MODE == 2)   // natural operand routing on the SAME distinct pair: lo - d1, hi - d0
+        asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]"
+                     : "=v"(got[i]) : "v"(x[i]), "v"(dpair));
+      else {
+        f32x2 dd = {dpair[1], dpair[1]};
+        asm volatile("" : "+v"(dd));
+        asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]"
+                     : "=v"(got[i]) : "v"(x[i]), "v"(dd));
+      }
+      if (TRAFFIC & 2) tr = __builtin_amdgcn_exp2f(tr * 0.001f) + 1.f;   // between the packed ops
+      if ((TRAFFIC & 1) && (i & 3) == 3) {
+        acc[i >> 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, acc[i >> 2], 0, 0, 0);
+        // NOPS wait states between the MFMA and the next packed op (asm volatile keeps order)
+        if (NOPS >= 1) asm volatile("s_nop %0" :: "n"(NOPS > 8 ? 7 : NOPS - 1));
+        if (NOPS > 8) asm volatile("s_nop %0" :: "n"(NOPS - 9));
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const bool blo = __builtin_bit_cast(unsigned, got[i][0]) != __builtin_bit_cast(unsigned, want[i][0]);
+      const bool bhi = __builtin_bit_cast(unsigned, got[i][1]) != __builtin_bit_cast(unsigned, want[i][1]);
+      nbad_lo += blo;
+      nbad_hi += bhi;
+      // what did a wrong lane compute?  x - d1 (the LOW dword of the pair) in both halves?
+      float alt_lo, alt_hi;
+      asm volatile("v_sub_f32 %0, %1, %2" : "=v"(alt_lo) : "v"(x[i][0]), "v"(dpair[0]));
+      asm volatile("v_sub_f32 %0, %1, %2" : "=v"(alt_hi) : "v"(x[i][1]), "v"(dpair[0]));
+      if (blo && MODE == 1 && TRAFFIC == 1 && NOPS == 0) {
+        const unsigned long long slot = atomicAdd(&bad[9], 1ull);
+        if (slot < 16) {
+          float* dbg = reinterpret_cast<float*>(bad + 16) + slot * 8;
+          dbg[0] = x[i][0]; dbg[1] = got[i][0]; dbg[2] = want[i][0]; dbg[3] = dpair[0];
+          dbg[4] = dpair[1]; dbg[5] = d0_prev; dbg[6] = (float)lane; dbg[7] = (float)(it * 100 + i);
+        }
+      }
+      nalt += (blo && __builtin_bit_cast(unsigned, got[i][0]) == __builtin_bit_cast(unsigned, alt_lo)) +
+              (bhi && __builtin_bit_cast(unsigned, got[i][1]) == __builtin_bit_cast(unsigned, alt_hi));
+    }
+  }
+  if (nbad_lo) atomicAdd(&bad[row], nbad_lo);
+  if (nbad_hi) atomicAdd(&bad[4 + row], nbad_hi);
+  if (nalt) atomicAdd(&bad[8], nalt);
+  float s = tr;
+  for (int m = 0; m < 4; ++m) s += acc[m][0] + acc[m][3];
+  if (s == 12345.678f) sink[0] = s;   // keep the side traffic alive
+}
+
+int main(int argc, char** argv) {
+  const int iters = argc > 1 ? atoi(argv[1]) : 200;
+  std::vector<float> h(4096);
+  for (int i = 0; i < 4096; ++i) h[i] = (float)((i * 2654435761u) >> 8 & 0xffff) / 4096.f - 8.f;
+  float *in, *sink;
+  unsigned long long* bad;
+  hipMalloc(&in, 4096 * 4); hipMalloc(&sink, 4); hipMalloc(&bad, 1024);
+  hipMemcpy(in, h.data(), 4096 * 4, hipMemcpyHostToDevice);
+  struct Case { const char* name; void (*fn)(const float*, unsigned long long*, float*, int); };
+  const Case cases[] = {
+      {"op_sel:[0,1] (both halves read the HIGH dword of src1), MFMA + exp beside", k<1, 3>},
+      {"op_sel:[0,1], exp only beside", k<1, 2>},
+      {"op_sel:[0,1], MFMA only beside", k<1, 1>},
+      {"op_sel:[0,1], nothing beside", k<1, 0>},
+      {"op_sel:[0,1], MFMA only beside, 16 wait states (s_nop) after each MFMA", k<1, 1, 16>},
+      {"op_sel:[0,1], MFMA only by OTHER waves (odd waves MFMA-only, even waves packed-only)", k<1, 4>},
+      {"no op_sel, distinct (d1, d0) pair: lo - d1, hi - d0, MFMA + exp beside", k<2, 3>},
+      {"no op_sel, (d, d) pair, MFMA + exp beside", k<0, 3>}};
+  for (const Case& c : cases) {
+    unsigned long long total[9] = {0};
+    for (int rep = 0; rep < 20; ++rep) {
+      hipMemset(bad, 0, 1024);
+      hipLaunchKernelGGL(c.fn, dim3(768), dim3(256), 0, 0, in, bad, sink, iters);
+      unsigned long long hb[9];
+      hipMemcpy(hb, bad, 72, hipMemcpyDeviceToHost);
+      for (int i = 0; i < 9; ++i) total[i] += hb[i];
+      if (rep == 0) {
+        unsigned long long cnt;
+        float dbg[128];
+        hipMemcpy(&cnt, bad + 9, 8, hipMemcpyDeviceToHost);
+        hipMemcpy(dbg, bad + 16, 512, hipMemcpyDeviceToHost);
+        for (unsigned long long j = 0; j < cnt && j < 8; ++j)
+          printf("      sample: lane %2.0f step %5.0f  x %.6f got %.6f want %.6f -> d used %.6f | d1(lo) %.6f d0(hi) %.6f d0 of the previous iteration %.6f\n",
+                 dbg[j * 8 + 6], dbg[j * 8 + 7], dbg[j * 8], dbg[j * 8 + 1], dbg[j * 8 + 2],
+                 dbg[j * 8] - dbg[j * 8 + 1], dbg[j * 8 + 3], dbg[j * 8 + 4], dbg[j * 8 + 5]);
+      }
+    }
+    printf("%s\n   mismatching LOW halves per 16-lane row: %llu %llu %llu %llu   HIGH halves: %llu %llu %llu %llu"
+           "   of these equal to x - (LOW dword of src1): %llu\n",
+           c.name, total[0], total[1], total[2], total[3], total[4], total[5], total[6], total[7], total[8]);
+  }
+  printf("(20 launches x 768 workgroups x %d iterations x 16 packed subtracts per lane each)\n", iters);
+  return 0;
+}
