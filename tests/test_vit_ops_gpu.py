@@ -48,11 +48,12 @@ def test_gemm_bias_bf16(M, N, K):
                                rtol=2 ** -8, atol=2e-3)
 
 
-@pytest.mark.parametrize('cfg', [1, 2, 5, 7, 11, 12, 13, 14])
+@pytest.mark.parametrize('cfg', [1, 2, 5, 7, 8, 9, 10, 11, 12, 13, 14])
 @pytest.mark.parametrize('M,N,K', [(5406, 2304, 768), (300, 1024, 4096), (901, 768, 192),
                                    (257, 520, 64), (1, 4, 64)])
 def test_gemm_every_big_tile_configuration(cfg, M, N, K):
-    """The DMA-ring kernels (1..7: whole K = 64 stages; 11..14: ring of K = 32 granules,
+    """The DMA-ring kernels (1..7: whole K = 64 stages, eight waves; 8..10: the same with
+    sixteen waves; 11..14: ring of K = 32 granules,
     four slots, three in flight) forced through veon_gemm_ring_set, on ragged shapes
     (M, N not multiples of the tile, K of one to 64 stages): all three epilogue
     families against fp32 references."""

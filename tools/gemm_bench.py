@@ -26,7 +26,7 @@ if os.environ.get('SPLITK_EMU'):   # split-K emulated as more rows with a shorte
               ('B fc2 /2', 10812, 768, 1536), ('B fc2 /3', 16218, 768, 1024),
               ('L qkv /2', 10812, 3072, 512), ('B qkv /2', 10812, 2304, 384)]
 NAMES = {0: 'small', 1: '256x256', 2: '192x192', 3: '128x192', 4: '128x256', 5: '256x192',
-         6: '128x128', 7: '256x128', 11: 'g256x256', 12: 'g256x128', 13: 'g128x256',
+         6: '128x128', 7: '256x128', 8: 'w16-256x256', 9: 'w16-256x128', 10: 'w16-128x256', 11: 'g256x256', 12: 'g256x128', 13: 'g128x256',
          14: 'g128x128'}
 if os.environ.get('GEMM_CFGS'):
     NAMES = {int(c): NAMES[int(c)] for c in os.environ['GEMM_CFGS'].split(',')}
@@ -87,6 +87,16 @@ def main():
             t_pl = min(timeit(lambda: vit_ops.linear_residual_(xr, a, w, b, None))
                        for _ in range(rounds))
             sk = ' | resid: split-K %6.1f plain %6.1f' % (t_sk, t_pl)
+        if os.environ.get('RESID_CFGS'):      # the residual epilogue under forced tiles
+            xr = torch.randn(M, N, device=dev, generator=g)
+            parts = []
+            for cfg in CFGS:
+                L.veon_gemm_ring_set(cfg)
+                parts.append('%s %.1f' % (NAMES[cfg], min(
+                    timeit(lambda: vit_ops.linear_residual_(xr, a, w, b, None))
+                    for _ in range(rounds))))
+            L.veon_gemm_ring_set(-1)
+            sk += ' | resid by tile: ' + ' '.join(parts)
         line = '%-10s %5dx%4dx%4d |' % (name, M, N, K)
         for cfg in CFGS:
             t = min(res[cfg][1:])

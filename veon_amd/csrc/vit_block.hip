@@ -1337,9 +1337,25 @@ inline int gemm_ring_config(int M, int N, int K) {
     return (int64_t)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
   };
   const int64_t lo = 160, hi = kNumCU;
-  if (wgs(256, 256) >= lo && wgs(256, 256) <= hi) return 1;
-  if (wgs(256, 128) >= lo && wgs(256, 128) <= hi) return 7;
+  // round 3: the same tiles with SIXTEEN waves of 64 x 64 / 64 x 32 (configs 8 / 9)
+  // instead of eight of 128 x 64 / 64 x 64 (1 / 7): ViT-B qkv 28.4 vs 31.3 us, ViT-L
+  // fc2 (bf16 out) 58.6 vs 66.1, HSA heads 12.0 vs 13.1
+  // (profiles/r03_gemm_bench_16waves.txt) -- more waves per SIMD hide the LDS-read ->
+  // MFMA latency that eight could not, as in the conv kernel
+  static const bool w16 = [] { const char* e = getenv("VEON_GEMM_W16"); return !e || atoi(e); }();
+  if (wgs(256, 256) >= lo && wgs(256, 256) <= hi) return w16 ? 8 : 1;
+  if (wgs(256, 128) >= lo && wgs(256, 128) <= hi) return w16 ? 9 : 7;
   return 0;
+}
+
+// The residual epilogue (fp32 read-modify-write of the stream, issued by every workgroup
+// at the same time in a one-round grid) costs the big tiles more than their main loop
+// gains -- except for the long-K fc2 of ViT-L: 63.4 us on the 16-wave 256 x 128 tile
+// against 70.0 small-tile and 65.8 split-K.
+inline int gemm_resid_config(int M, int N, int K) {
+  const int64_t w = (int64_t)((M + 255) / 256) * ((N + 127) / 128);
+  static const bool w16 = [] { const char* e = getenv("VEON_GEMM_W16"); return !e || atoi(e); }();
+  return (w16 && K >= 4096 && w >= 160 && w <= kNumCU) ? 9 : 0;
 }
 }  // namespace
 
@@ -1492,7 +1508,8 @@ int veon_vit_gemm(const void* a_bf16, const void* w_bf16, const float* bias,
     // workgroup at the same time in a one-round grid, costs the big tiles more
     // than their main loop gains: measured 30 vs 25 us on the ViT-L proj)
     int sel = g_gemm_ring >= 0 ? g_gemm_ring
-                    : epilogue == EPI_RESID ? 0 : gemm_ring_config(M, N, K);
+                    : epilogue == EPI_RESID ? gemm_resid_config(M, N, K)
+                                            : gemm_ring_config(M, N, K);
     if (epilogue == EPI_AFFINE_SIGM) sel = 0;   // small-tile kernel only
     // the ring kernel addresses both matrices with 32-bit byte offsets
     if ((int64_t)M * K * 2 >= (1ll << 31) || (int64_t)N * K * 2 >= (1ll << 31)) sel = 0;
@@ -1555,6 +1572,9 @@ int veon_vit_gemm(const void* a_bf16, const void* w_bf16, const float* bias,
       case 4: VEON_RING(EPI, 2, 4, 4, 4, 3); break; /* 128 x 256 */ \
       case 5: VEON_RING(EPI, 2, 4, 8, 3, 2); break; /* 256 x 192 */ \
       case 7: VEON_RING(EPI, 4, 2, 4, 4, 3); break; /* 256 x 128 */ \
+      case 8: VEON_RING(EPI, 4, 4, 4, 4, 2); break; /* 256 x 256, 16 waves of 64 x 64 */ \
+      case 9: VEON_RING(EPI, 4, 4, 4, 2, 3); break; /* 256 x 128, 16 waves of 64 x 32 */ \
+      case 10: VEON_RING(EPI, 4, 4, 2, 4, 3); break; /* 128 x 256, 16 waves of 32 x 64 */ \
       default: VEON_RING(EPI, 2, 4, 4, 2, 4); break; /* 128 x 128 */ \
     }                                                               \
   } while (0)
@@ -1712,7 +1732,9 @@ int veon_vit_block(float* x, const veon_vit_block_weights* w,
   const int64_t slab_need = (g_gemm_ring < 0 && w->mlp_dim >= 4096)
                                 ? veon_vit_gemm_splitk_plan(M, d, w->mlp_dim, nullptr)
                                 : 0;
-  if (slab_need > 0 && slab_need <= al(M64 * 3 * d * 2))
+  // (the split-K form stays an entry point of its own; the 16-wave tile beats it here)
+  if (slab_need > 0 && slab_need <= al(M64 * 3 * d * 2) &&
+      gemm_resid_config(M, d, w->mlp_dim) == 0)
     return veon_vit_gemm_splitk(u, w->w_fc2, w->b_fc2, w->gamma2, x, M, d, w->mlp_dim, qkv,
                                 al(M64 * 3 * d * 2), sync_words, kSplitKSyncInts, stream);
   return veon_vit_gemm(u, w->w_fc2, w->b_fc2, w->gamma2, x, nullptr, M, d,
