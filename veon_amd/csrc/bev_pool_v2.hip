@@ -689,14 +689,24 @@ __global__ __launch_bounds__(256) void k_feat_nchw_to_nhwc(const T* __restrict__
   const T* ib = in + (int64_t)blockIdx.z * C * HW;
   T* ob = out + (int64_t)blockIdx.z * HW * C;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  for (int r = ty; r < 64; r += 4) {
-    const int c = c0 + r, p = p0 + tx;
-    if (c < C && p < HW) t[r][tx] = ib[(int64_t)c * HW + p];
+  // all sixteen loads of a thread in flight before the first LDS store: the kernel has
+  // 132 workgroups at S2 and is pure latency (8.6 us with a load -> store loop, a fifth
+  // of the pool kernel it feeds)
+  T v[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int c = c0 + ty + 4 * k, p = p0 + tx;
+    v[k] = (c < C && p < HW) ? ib[(int64_t)c * HW + p] : T(0);
   }
+#pragma unroll
+  for (int k = 0; k < 16; ++k) t[ty + 4 * k][tx] = v[k];
   __syncthreads();
-  for (int r = ty; r < 64; r += 4) {
-    const int p = p0 + r, c = c0 + tx;
-    if (p < HW && c < C) ob[(int64_t)p * C + c] = t[tx][r];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) v[k] = t[tx][ty + 4 * k];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int p = p0 + ty + 4 * k, c = c0 + tx;
+    if (p < HW && c < C) ob[(int64_t)p * C + c] = v[k];
   }
 }
 // ---------------------------------------------------------------------------
