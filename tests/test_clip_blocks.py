@@ -211,3 +211,54 @@ def test_rec_head_tail_blocks_on_mfma():
     want = t['clip_feat_proj']
     rel = ((outs['clip_feat_proj'] - want).norm() / want.norm()).item()
     assert rel < 2e-2, rel
+
+
+@pytest.mark.gpu
+def test_trunk_native_token_stream_equals_torch_tokens():
+    """ClipVisualTrunk._native_stream (patchify kernel + one MFMA GEMM onto the position
+    rows + fp32 LayerNorm kernel) against ``tokens`` (conv1 as an fp32 matmul, cat, add,
+    nn.LayerNorm): the same stream up to the half-precision rounding of the patch operands;
+    entry 0 of the trunk's outputs is that stream, and the blocks after it agree with the
+    torch blocks started from it.  Also with a resized position embedding and an image
+    whose size is not a multiple of the patch."""
+    torch.manual_seed(1)
+    dev = 'cuda:0'
+    m = clip_blocks.ClipVisualTrunk(224, 16, 768, 2, 12).to(dev).eval()
+    for shape in ((6, 3, 128, 352), (2, 3, 100, 70)):
+        img = torch.randn(*shape, device=dev)
+        with torch.no_grad():
+            want, hw = m.tokens(img)                       # (L, N, D)
+            s, hw2 = m._native_stream(img)                 # (N, L, D)
+            assert hw == hw2
+            got = s.permute(1, 0, 2)
+            rel = (got - want).norm() / want.norm()
+            assert rel < 4e-3, rel.item()
+            outs, _ = m(img, taps={0, 2})
+            assert torch.equal(outs[0], got)
+            assert outs[1] is None and outs[2] is not None
+            ref = want
+            for blk in m.resblocks:
+                ref = blk(ref)
+            assert (outs[2] - ref).norm() / ref.norm() < 1e-2
+
+
+def test_padded_attention_biases_equal_the_bordered_gram_matrices():
+    """AttnManipulateBlock.pad_class_token: the Gram matrices of the head embeddings with a
+    zero row in front ARE what ClipRecHead.build_attn_bias makes of the unpadded ones
+    (clip_utils/visual.py:287-292), and update_remaining_clip_feats passes them through."""
+    from veon_amd.models.semantic_net.hsa_network import AttnManipulateBlock
+    torch.manual_seed(3)
+    blk = AttnManipulateBlock(dim=64, mlp_dim=64, clip_dim=128, heads=2, dim_head=8,
+                              attn_layers=3, add_layers=1, supp_dim=32).eval()
+    x = torch.randn(2, 6 * 10, 64)
+    with torch.no_grad():
+        _, plain, supp = blk(x, (6, 10), (3, 5))
+        blk.pad_class_token = True
+        _, padded, supp2 = blk(x, (6, 10), (3, 5))
+    assert plain.shape == (3, 2, 2, 15, 15) and padded.shape == (3, 2, 2, 16, 16)
+    assert torch.equal(supp, supp2)
+    for t in range(3):
+        want = clip_blocks.ClipRecHead.build_attn_bias(plain[t])       # (B*H, L+1, L+1)
+        torch.testing.assert_close(padded[t].reshape(-1, 16, 16), want, rtol=1e-6, atol=1e-6)
+        assert float(padded[t][..., 0, :].abs().sum()) == 0.0
+        assert float(padded[t][..., :, 0].abs().sum()) == 0.0

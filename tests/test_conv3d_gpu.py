@@ -257,6 +257,43 @@ def test_conv2d_matches_torch(B, Cin, Cout, Y, X, mode, dtype):
     assert float(grid.abs().sum()) == 0.0
 
 
+@pytest.mark.parametrize('B,C,Y,X', [(1, 64, 5, 7), (6, 256, 36, 50), (2, 128, 9, 33)])
+def test_conv2d_second_residual_and_relu_output(B, C, Y, X):
+    """veon_conv2d_k3_bf16_ex: out = conv + bias + resid + resid2 and a second image
+    holding relu(out) -- FeatureFusionBlock's x0 + RCU1(x1) and the ReLU in front of the
+    next ResidualConvUnit (util/blocks.py:49-148) out of one epilogue.  Against torch in
+    fp64 on the bf16 operands; out_relu is the ReLU of the ROUNDED result (what a separate
+    pass over `out` would give); the halo of both outputs stays zero; each extra alone."""
+    g = torch.Generator().manual_seed(C + X)
+    xs = [_bf(torch.randn(B, C, Y, X, generator=g)).to(DEV) for _ in range(3)]
+    x, r1, r2 = (conv3d_ops.pack_image(t.to(torch.bfloat16)) for t in xs)
+    w = _bf(torch.randn(C, C, 3, 3, generator=g) * (9 * C) ** -0.5).to(DEV)
+    bias = torch.randn(C, generator=g).to(DEV)
+    wp = conv3d_ops.pack_weight2d(w)
+    shift = torch.zeros(wp.shape[0], device=DEV)
+    shift[:C] = bias
+    conv = F.conv2d(xs[0].double(), w.double(), bias.double(), padding=1)
+    out = conv3d_ops.PaddedImage(B, C, Y, X, DEV)
+    rel = conv3d_ops.PaddedImage(B, C, Y, X, DEV)
+    conv3d_ops.conv2d_k3(x, wp, None, shift, resid=r1, resid2=r2, out=out, out_relu=rel)
+    got = conv3d_ops.unpack_image(out, torch.float32, C)
+    _close(got, (conv + xs[1].double() + xs[2].double()).float())
+    assert torch.equal(conv3d_ops.unpack_image(rel, torch.float32, C), got.clamp_min(0))
+    for t in (out, rel):
+        grid = t.rows.view(B, Y + 2, X + 2, -1).float().clone()
+        grid[:, 1:-1, 1:-1] = 0
+        assert float(grid.abs().sum()) == 0.0
+    # each extra alone
+    one = conv3d_ops.unpack_image(conv3d_ops.conv2d_k3(x, wp, None, shift, resid=r1),
+                                  torch.float32, C)
+    only_relu = conv3d_ops.PaddedImage(B, C, Y, X, DEV)
+    o2 = conv3d_ops.conv2d_k3(x, wp, None, shift, resid=r1, out_relu=only_relu)
+    assert torch.equal(conv3d_ops.unpack_image(o2, torch.float32, C), one)
+    assert torch.equal(conv3d_ops.unpack_image(only_relu, torch.float32, C), one.clamp_min(0))
+    o3 = conv3d_ops.conv2d_k3(x, wp, None, shift, resid2=r2)
+    _close(conv3d_ops.unpack_image(o3, torch.float32, C), (conv + xs[2].double()).float())
+
+
 @pytest.mark.parametrize('size_in,size_out', [((4, 6), (8, 12)), ((9, 25), (18, 50)),
                                               ((144, 400), (252, 700)), ((5, 5), (1, 1))])
 def test_resize_bilinear_matches_interpolate(size_in, size_out):

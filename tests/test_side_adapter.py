@@ -189,3 +189,22 @@ def test_2d_branch_on_the_gpu():
                                  _clip_feats(trunk, images, CFG['clip_first_tail']))
     for k in ('mask_preds', 'sem_seg_ds', 'sem_embed_ds', 'sem_seg'):
         _close(out[k], g[k], tol=3e-2)
+
+
+def test_mask_decoder_inference_forms_equal_the_reference_einsum_and_linear():
+    """MLPMaskDecoder at inference writes the attention-bias contraction as a batched
+    matmul and the Linear(1, 1) bias scaling as a multiply-add (side_adapter.py); both
+    must give what the reference's einsum / nn.Linear give (the grad-enabled path)."""
+    from veon_amd.models.semantic_net.side_adapter import MLPMaskDecoder
+    torch.manual_seed(5)
+    dec = MLPMaskDecoder(in_channels=24, total_heads=3, total_layers=2, embed_channels=16,
+                         mlp_channels=16, mlp_num_layers=2, rescale_attn_bias=True).eval()
+    q, x = torch.randn(2, 7, 24), torch.randn(2, 24, 5, 6)
+    m_ref, a_ref = dec(q, x)
+    with torch.no_grad():
+        m_inf, a_inf = dec(q, x)
+    torch.testing.assert_close(m_inf, m_ref.detach(), rtol=1e-6, atol=1e-6)
+    assert len(a_inf) == len(a_ref) == 2
+    for a, b in zip(a_inf, a_ref):
+        assert a.shape == b.shape == (2, 3, 7, 5, 6)
+        torch.testing.assert_close(a, b.detach(), rtol=1e-5, atol=1e-6)
