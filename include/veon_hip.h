@@ -25,7 +25,9 @@
 extern "C" {
 #endif
 
-#define VEON_ABI_VERSION 1
+/* 2: veon_vit_block_weights grew the trailing field q_log2 (round 3); every entry point
+ * that existed under version 1 keeps its signature and meaning. */
+#define VEON_ABI_VERSION 2
 
 #define VEON_OK 0
 #define VEON_ERR_BAD_ARG 1    /* null pointer, negative size, unsupported shape */

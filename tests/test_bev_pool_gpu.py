@@ -79,7 +79,7 @@ def _run_fused(depth, feat_nhwc, ranks, shape, layout, table=False):
 
 def test_library_loaded_and_abi():
     L = _lib.lib()
-    assert L.veon_abi_version() == 1
+    assert L.veon_abi_version() == 2
     assert L.veon_status_string(0) == b'ok'
 
 

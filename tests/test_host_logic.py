@@ -46,7 +46,7 @@ def test_library_exports_every_declared_symbol():
         for name in declared:
             assert hasattr(lib, name), '%s lacks %s' % (os.path.basename(path), name)
         lib.veon_abi_version.restype = ctypes.c_int
-        assert lib.veon_abi_version() == 1          # host-only calls, no GPU needed
+        assert lib.veon_abi_version() == 2          # host-only calls, no GPU needed
         assert lib.veon_half_mode() == (1 if flavour == 'fp16' else 0)
 
 
