@@ -61,14 +61,25 @@ __global__ __launch_bounds__(256, 3) void k(const float* __restrict__ in, unsign
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       float lo, hi;
-      asm volatile("v_sub_f32 %0, %1, %2" : "=v"(lo) : "v"(x[i][0]), "v"(dpair[MODE == 2 ? 0 : 1]));
-      asm volatile("v_sub_f32 %0, %1, %2" : "=v"(hi) : "v"(x[i][1]), "v"(dpair[1]));
+      // MODE 1: lo - d0, hi - d0 | 2: lo - d1, hi - d0 | 3 (op_sel_hi:[1,0], the broadcast
+      // form compilers emit everywhere): lo - d1, hi - d1 | 4 (op_sel:[1,0], src0 crossed):
+      // x.hi - d1, x.hi - d0 | 0: (d, d) pair
+      constexpr int XL = MODE == 4 ? 1 : 0, DL = (MODE == 2 || MODE == 3 || MODE == 4) ? 0 : 1,
+                    DH = MODE == 3 ? 0 : 1;
+      asm volatile("v_sub_f32 %0, %1, %2" : "=v"(lo) : "v"(x[i][XL]), "v"(dpair[DL]));
+      asm volatile("v_sub_f32 %0, %1, %2" : "=v"(hi) : "v"(x[i][1]), "v"(dpair[DH]));
       want[i][0] = lo; want[i][1] = hi;
     }
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       if (MODE == 1)
         asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]"
+                     : "=v"(got[i]) : "v"(x[i]), "v"(dpair));
+      else if (MODE == 3)
+        asm volatile("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]"
+                     : "=v"(got[i]) : "v"(x[i]), "v"(dpair));
+      else if (MODE == 4)
+        asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]"
                      : "=v"(got[i]) : "v"(x[i]), "v"(dpair));
       else if (MODE == 2)   // natural operand routing on the SAME distinct pair: lo - d1, hi - d0
         asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]"
@@ -133,6 +144,8 @@ int main(int argc, char** argv) {
       {"op_sel:[0,1], nothing beside", k<1, 0>},
       {"op_sel:[0,1], MFMA only beside, 16 wait states (s_nop) after each MFMA", k<1, 1, 16>},
       {"op_sel:[0,1], MFMA only by OTHER waves (odd waves MFMA-only, even waves packed-only)", k<1, 4>},
+      {"op_sel_hi:[1,0] (HIGH half reads the LOW dword of src1: the broadcast form), MFMA beside", k<3, 1>},
+      {"op_sel:[1,0] (LOW half reads the HIGH dword of src0), MFMA beside", k<4, 1>},
       {"no op_sel, distinct (d1, d0) pair: lo - d1, hi - d0, MFMA + exp beside", k<2, 3>},
       {"no op_sel, (d, d) pair, MFMA + exp beside", k<0, 3>}};
   for (const Case& c : cases) {
