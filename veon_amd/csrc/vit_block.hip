@@ -1592,8 +1592,18 @@ int veon_vit_gemm(const void* a_bf16, const void* w_bf16, const float* bias,
       return launch_status();
     }
   }
-  const int wm = 4, wn = 2;
-  const int mt = ((int64_t)((M + 63) / 64) * ((N + 127) / 128) > 8 * kNumCU) ? 2 : 1;
+  int wm = 4, wn = 2;
+  int mt = ((int64_t)((M + 63) / 64) * ((N + 127) / 128) > 8 * kNumCU) ? 2 : 1;
+  {
+    // experiment knob (tools/gemm_bench.py): VEON_GEMM_SMALL=wm,wn,mt forces the small-tile
+    // kernel's shape among the instantiated ones
+    static const int forced = [] {
+      const char* e = getenv("VEON_GEMM_SMALL");
+      int a = 0, b = 0, c = 0;
+      return (e && sscanf(e, "%d,%d,%d", &a, &b, &c) == 3) ? a * 100 + b * 10 + c : 0;
+    }();
+    if (forced) { wm = forced / 100; wn = (forced / 10) % 10; mt = forced % 10; }
+  }
   const int bm = wm * 16 * mt, bn = 64 * wn;
   const dim3 grid((unsigned)((N + bn - 1) / bn), (unsigned)((M + bm - 1) / bm));
 #define VEON_LAUNCH_GEMM(EPI, WM, WN, MT)                                      \
@@ -1611,6 +1621,9 @@ int veon_vit_gemm(const void* a_bf16, const void* w_bf16, const float* bias,
 #define VEON_LAUNCH_GEMM_MT(EPI)                                               \
   do {                                                                         \
     if (VEON_T(4, 2, 2)) VEON_LAUNCH_GEMM(EPI, 4, 2, 2);                       \
+    else if (VEON_T(4, 4, 1)) VEON_LAUNCH_GEMM(EPI, 4, 4, 1);                  \
+    else if (VEON_T(4, 4, 2)) VEON_LAUNCH_GEMM(EPI, 4, 4, 2);                  \
+    else if (VEON_T(8, 2, 1)) VEON_LAUNCH_GEMM(EPI, 8, 2, 1);                  \
     else VEON_LAUNCH_GEMM(EPI, 4, 2, 1);                                       \
   } while (0)
   switch (epilogue) {
