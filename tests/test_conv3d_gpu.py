@@ -586,3 +586,18 @@ def test_conv2d_stride2_matches_torch(shape):
     rows = out.rows.view(B, out.shape[2] + 2, out.shape[3] + 2, -1)
     assert not rows[:, 0].any() and not rows[:, -1].any()
     assert not rows[:, :, 0].any() and not rows[:, :, -1].any()
+
+
+def test_body_conv_is_deterministic_under_load():
+    """The 3x3x3 body conv at the VEON shape (249 workgroups of 12 waves, one per CU),
+    30 launches on the same operands: bit-identical."""
+    g = torch.Generator().manual_seed(7)
+    x = _bf(torch.randn(1, 256, 8, 100, 100, generator=g)).to(DEV)
+    w = _bf(torch.randn(256, 256, 3, 3, 3, generator=g) * (27 * 256) ** -0.5).to(DEV)
+    vol = conv3d_ops.pack(x.to(torch.bfloat16))
+    wp = conv3d_ops.pack_weight(w)
+    scale = torch.rand(256, generator=g).to(DEV) + 0.5
+    shift = torch.randn(256, generator=g).to(DEV)
+    first = conv3d_ops.conv3d_k3(vol, wp, scale, shift, relu=True).rows.clone()
+    for _ in range(30):
+        assert torch.equal(conv3d_ops.conv3d_k3(vol, wp, scale, shift, relu=True).rows, first)

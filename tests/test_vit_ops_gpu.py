@@ -343,3 +343,24 @@ def test_layernorm_f32_matches_torch(T, d):
     got = vit_ops.layernorm_f32(x, w, b, 1e-5)
     want = F.layer_norm(x, (d,), w, b, 1e-5)
     torch.testing.assert_close(got, want, rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize('M,N,K,epi', [(5406, 2304, 768, vit_ops.EPI_BF16),      # 16-wave ring tile
+                                       (5406, 3072, 768, vit_ops.EPI_GELU),      # small-tile kernel
+                                       (5406, 1024, 4096, 'resid')])             # 16-wave, residual
+def test_gemm_is_deterministic_under_load(M, N, K, epi):
+    """Same operands, 40 launches on a full chip, bit-identical outputs: the GEMM kernels
+    accumulate in a fixed order, so any difference would be a hardware / scheduling fault
+    of the kind DESIGN 4b describes for the attention kernel."""
+    a = _rand(M, K, seed=51).to(torch.bfloat16)
+    w = (_rand(N, K, seed=52) * K ** -0.5).to(torch.bfloat16)
+    bias = _rand(N, seed=53)
+    x0 = _rand(M, N, seed=54)
+
+    def run():
+        if epi == 'resid':
+            return vit_ops.linear_residual_(x0.clone(), a, w, bias, None)
+        return vit_ops.linear(a, w, bias, epi)
+    first = run().clone()
+    for _ in range(40):
+        assert torch.equal(run(), first)
